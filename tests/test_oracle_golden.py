@@ -1,0 +1,104 @@
+"""The oracle (oracle/bpr_oracle.c) against the fixtures produced by the reference's own sampler and
+Evaluator (tests/golden/gen_golden.py).  CPU only."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from fashionvisualexpl_recommend_amd import synth
+from oracle import oracle as orc
+
+
+def _golden(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "golden.json")))
+
+
+def _tiny(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "dataset_tiny.json")))
+
+
+# ---- RNG front-ends against CPython / NumPy themselves (neutral check) ---------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 6, 1000, 100000])
+def test_py_shuffle_matches_cpython(n):
+    for seed in (0, 1, 12345):
+        x = list(range(n))
+        random.seed(seed)
+        random.shuffle(x)
+        assert orc.py_shuffle(seed, n).tolist() == x
+
+
+@pytest.mark.parametrize("high", [1, 2, 9, 2000, 50000, 10 ** 6, 5 * 10 ** 6, 2 ** 31 - 1])
+def test_np_randint_matches_numpy_legacy(high):
+    for seed in (0, 7):
+        np.random.seed(seed)
+        want = np.array([np.random.randint(high) for _ in range(3000)])
+        assert np.array_equal(orc.np_randint(seed, high, 3000), want)
+
+
+# ---- index stream vs the reference's DataLoader.all_triple_batches ----------------------------------------------
+def test_stream_tiny_bit_exact(golden_dir):
+    ds = _tiny(golden_dir)
+    g = np.load(os.path.join(golden_dir, "stream_tiny.npz"))
+    U, I, bs, ep = g["meta"].tolist()
+    u, i, j = orc.sample_ref_stream(ds["loaded_train"], I, bs, ep)
+    assert len(u) == _golden(golden_dir)["tiny"]["n"] == 32
+    assert np.array_equal(np.stack([u, i, j]), g["uij"])
+
+
+def test_stream_short_no_early_return(golden_dir):
+    """N < batch_size: (N//bs)*bs*epochs == 0, so dataset.py:109 never fires and all epochs are emitted."""
+    ds = _tiny(golden_dir)
+    g = np.load(os.path.join(golden_dir, "stream_short.npz"))
+    U, I, bs, ep = g["meta"].tolist()
+    u, i, j = orc.sample_ref_stream(ds["loaded_train"], I, bs, ep)
+    assert len(u) == 48
+    assert np.array_equal(np.stack([u, i, j]), g["uij"])
+
+
+def test_stream_c1_sha256(golden_dir):
+    """BASELINE.md section 2 known answer: 99 840 triplets, sha256 f77db4ef..."""
+    g = np.load(os.path.join(golden_dir, "stream_c1_head.npz"))
+    gj = _golden(golden_dir)["c1"]
+    tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
+    u, i, j = orc.sample_ref_stream(tr, 2000, 256, 5)
+    assert len(u) == gj["n"] == 99840
+    arr = np.stack([u, i, j]).astype(np.int64)
+    assert np.array_equal(arr[:, :4096], g["uij"])
+    assert np.array_equal(arr[:, -256:], g["tail"])
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == gj["sha256_int64_3xN"]
+    assert gj["sha256_int64_3xN"].startswith("f77db4efcb76dd27")
+
+
+def test_stream_properties():
+    tr, va, te = synth.make_interactions(50, 40, per_user=12, seed=3)
+    u, i, j = orc.sample_ref_stream(tr, 40, 16, 3)
+    assert len(u) == (50 * 10 // 16) * 16 * 3
+    for a, b, c in zip(u, i, j):
+        assert b in tr[a] and c not in tr[a] and 0 <= c < 40
+
+
+# ---- metrics vs the reference's Evaluator ----------------------------------------------------------------------
+KEYS = ["hr_v", "p_v", "r_v", "auc_v", "ndcg_v", "hr_t", "p_t", "r_t", "ndcg_t"]
+
+
+def test_eval_tiny_with_ties(golden_dir):
+    ds = _tiny(golden_dir)
+    want = _golden(golden_dir)["eval_tiny"]
+    sc = np.load(os.path.join(golden_dir, "eval_tiny_scores.npy"))
+    got = orc.evaluate(sc, ds["loaded_train"], ds["loaded_val"], ds["loaded_test"], want["K"])
+    for k in KEYS:
+        assert got[k] == pytest.approx(want["results"][k], abs=1e-12), k
+    # Evaluator.py:220 stores auc_v under 'auc_t'; the oracle returns the true auc_t
+    assert want["results"]["auc_t"] == want["results"]["auc_v"]
+
+
+def test_eval_c1(golden_dir):
+    want = _golden(golden_dir)["eval_c1"]
+    tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
+    sc = np.random.RandomState(want["score_seed"]).standard_normal((1000, 2000)).astype(np.float32)
+    got = orc.evaluate(sc, tr, va, te, want["K"])
+    for k in KEYS:
+        assert got[k] == pytest.approx(want["results"][k], abs=1e-12), k
