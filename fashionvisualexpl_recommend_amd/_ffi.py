@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI in include/bprx.h (libbprx.so, built in-tree by build.py).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the engine raises.
+PyTorch is used by callers only for device memory, streams and torch.distributed; nothing here takes a
+torch type -- pointers are plain integers (tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbprx.so")
+ABI_VERSION = 1
+
+MODEL = {"bprmf": 0, "vbpr": 1}
+OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
+FEAT_DTYPE = {"fp32": 0, "bf16": 1}
+E_RANGE = -4
+
+
+class BprxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbprx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("model", C.c_int32), ("num_users", C.c_int32), ("num_items", C.c_int32),
+                ("embed_k", C.c_int32), ("embed_d", C.c_int32), ("feat_dim", C.c_int32), ("feat_dtype", C.c_int32),
+                ("optimizer", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int64),
+                ("lr", C.c_float), ("reg", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float)]
+
+
+TABLE_FIELDS = ["Gu", "Gi", "Bi", "Tu", "F", "E", "Bp", "m_Gu", "v_Gu", "m_Gi", "v_Gi", "m_Bi", "v_Bi",
+                "m_Tu", "v_Tu", "m_E", "v_E", "m_Bp", "v_Bp"]
+
+
+class Tables(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TABLE_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    """Load libbprx.so; raise loudly when it is absent (the product path has no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libbprx.so not found at %s: build it with `python -m fashionvisualexpl_recommend_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+    sig = {
+        "bprx_abi_version": (C.c_int, []),
+        "bprx_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
+        "bprx_destroy": (C.c_int, [vp]),
+        "bprx_last_error": (C.c_char_p, [vp]),
+        "bprx_bind_tables": (C.c_int, [vp, C.POINTER(Tables)]),
+        "bprx_set_hyper": (C.c_int, [vp, f32, f32]),
+        "bprx_set_adam_step": (C.c_int, [vp, i64]),
+        "bprx_get_adam_step": (i64, [vp]),
+        "bprx_score_pairs": (C.c_int, [vp, vp, vp, i64, vp, vp]),
+        "bprx_step": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
+        "bprx_step_begin": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+        "bprx_dense_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
+        "bprx_step_end": (C.c_int, [vp, vp, vp]),
+        "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
+        "bprx_sync_check": (C.c_int, [vp, vp]),
+        "bprx_sampler_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "bprx_sampler_destroy": (C.c_int, [vp]),
+        "bprx_sampler_count": (i64, [vp, i32, i32]),
+        "bprx_sampler_ref_stream": (i64, [vp, i32, i32, u32, u32, vp, vp, vp, i64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)       # AttributeError here == header/library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if L.bprx_abi_version() != ABI_VERSION:
+        raise ImportError("libbprx.so ABI %d != binding ABI %d" % (L.bprx_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper",
+           "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
+           "bprx_dense_grad", "bprx_step_end", "bprx_score_block", "bprx_sync_check", "bprx_sampler_create",
+           "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]
+
+
+def check(handle, rc):
+    if rc < 0:
+        msg = lib().bprx_last_error(handle)
+        raise BprxError(rc, msg.decode() if msg else "?")
+    return rc

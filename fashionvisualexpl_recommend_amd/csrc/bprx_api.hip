@@ -1,0 +1,244 @@
+// bprx_api.hip -- host side of the C ABI (include/bprx.h): handle, scratch, step orchestration.
+#include <math.h>
+#include <new>
+
+#include "bprx_internal.h"
+
+static char g_create_err[512] = "";
+
+extern "C" int bprx_abi_version(void) { return BPRX_ABI_VERSION; }
+
+extern "C" const char *bprx_last_error(const bprx_handle *h) { return h ? h->err : g_create_err; }
+
+template <typename T>
+static hipError_t dalloc_zero(T **p, size_t n) {
+  *p = nullptr;
+  if (n == 0) return hipSuccess;
+  hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+  if (e != hipSuccess) return e;
+  return hipMemset(*p, 0, n * sizeof(T));
+}
+
+static void free_scratch(bprx_handle *h) {
+  void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
+                  h->P,   h->W,   h->Ppair, h->Et, h->dEp, h->part};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+}
+
+extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
+#define CFAIL(code, ...)                                        \
+  do {                                                          \
+    snprintf(g_create_err, sizeof(g_create_err), __VA_ARGS__);  \
+    return (code);                                              \
+  } while (0)
+  if (!cfg || !out) CFAIL(BPRX_E_INVALID, "bprx_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != BPRX_ABI_VERSION)
+    CFAIL(BPRX_E_INVALID, "bprx_create: abi_version %d, library is %d", cfg->abi_version, BPRX_ABI_VERSION);
+  if (cfg->model != BPRX_MODEL_BPRMF && cfg->model != BPRX_MODEL_VBPR) CFAIL(BPRX_E_INVALID, "unknown model %d", cfg->model);
+  if (cfg->optimizer != BPRX_OPT_SGD && cfg->optimizer != BPRX_OPT_ADAM_TF23)
+    CFAIL(BPRX_E_INVALID, "unknown optimizer %d", cfg->optimizer);
+  if (cfg->num_users <= 0 || cfg->num_items <= 0 || cfg->embed_k <= 0 || cfg->max_batch <= 0)
+    CFAIL(BPRX_E_INVALID, "num_users, num_items, embed_k and max_batch must be positive");
+  const bool vb = cfg->model == BPRX_MODEL_VBPR;
+  if (vb) {
+    if (cfg->embed_d <= 0 || cfg->feat_dim <= 0) CFAIL(BPRX_E_INVALID, "VBPR needs embed_d > 0 and feat_dim > 0");
+    if (cfg->embed_d > 271) CFAIL(BPRX_E_INVALID, "embed_d %d > 271 unsupported", cfg->embed_d);
+    if (cfg->feat_dtype != BPRX_F_FP32 && cfg->feat_dtype != BPRX_F_BF16) CFAIL(BPRX_E_INVALID, "unknown feat_dtype");
+    if (cfg->feat_dtype == BPRX_F_BF16 && cfg->feat_dim % 128 != 0)
+      CFAIL(BPRX_E_INVALID, "bf16 features need feat_dim %% 128 == 0 (got %d)", cfg->feat_dim);
+  }
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e != hipSuccess) CFAIL(BPRX_E_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
+
+  bprx_handle *h = new (std::nothrow) bprx_handle();
+  if (!h) CFAIL(BPRX_E_NOMEM, "out of host memory");
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg;
+  if (!vb) { h->cfg.embed_d = 0; h->cfg.feat_dim = 0; }
+  const size_t U = cfg->num_users, I = cfg->num_items, k = cfg->embed_k, d = h->cfg.embed_d, D = h->cfg.feat_dim;
+  const size_t MB = cfg->max_batch;
+  bool ok = true;
+#define A(call) ok = ok && ((e = (call)) == hipSuccess)
+  A(dalloc_zero(&h->dGu, U * k));
+  A(dalloc_zero(&h->dGi, I * k));
+  A(dalloc_zero(&h->dBi, I));
+  A(dalloc_zero(&h->flagU, U));
+  A(dalloc_zero(&h->flagI, I));
+  A(dalloc_zero(&h->lossb, MB));
+  A(dalloc_zero(&h->loss_acc, (size_t)4));
+  A(dalloc_zero(&h->errflag, (size_t)1));
+  if (vb) {
+    h->PS = 16 * (int)((d + 1 + 15) / 16);
+    const size_t PS = h->PS;
+    // split-K of the backward projection: about 1024 workgroups over D/128 column ranges
+    int mr = (int)((D + 127) / 128);
+    h->SK = (1024 + mr - 1) / mr;
+    if (h->SK > 64) h->SK = 64;
+    if (h->SK < 1) h->SK = 1;
+    A(dalloc_zero(&h->dTu, U * d));
+    A(dalloc_zero(&h->P, I * PS));
+    A(dalloc_zero(&h->W, I * PS));
+    A(dalloc_zero(&h->Ppair, MB * PS));
+    A(dalloc_zero((uint16_t **)&h->Et, PS * D));
+    A(dalloc_zero(&h->dEp, D * d + D));
+    A(dalloc_zero(&h->part, (size_t)h->SK * D * PS));
+  }
+#undef A
+  if (!ok) {
+    snprintf(g_create_err, sizeof(g_create_err), "scratch allocation failed: %s", hipGetErrorString(e));
+    free_scratch(h);
+    delete h;
+    return BPRX_E_NOMEM;
+  }
+  *out = h;
+  return BPRX_OK;
+#undef CFAIL
+}
+
+extern "C" int bprx_destroy(bprx_handle *h) {
+  if (!h) return BPRX_OK;
+  (void)hipSetDevice(h->cfg.device);
+  free_scratch(h);
+  delete h;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
+  if (!h || !t) return BPRX_E_INVALID;
+  if (!t->Gu || !t->Gi || !t->Bi) BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: Gu, Gi, Bi are required");
+  const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  if (vb && (!t->Tu || !t->F || !t->E || !t->Bp)) BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: VBPR needs Tu, F, E, Bp");
+  if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
+    if (!t->m_Gu || !t->v_Gu || !t->m_Gi || !t->v_Gi || !t->m_Bi || !t->v_Bi)
+      BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: adam_tf23 needs m_/v_ slots for Gu, Gi, Bi");
+    if (vb && (!t->m_Tu || !t->v_Tu || !t->m_E || !t->v_E || !t->m_Bp || !t->v_Bp))
+      BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: adam_tf23 needs m_/v_ slots for Tu, E, Bp");
+  }
+  if (((uintptr_t)t->Gu | (uintptr_t)t->Gi | (uintptr_t)t->Tu | (uintptr_t)t->F | (uintptr_t)t->E) & 15)
+    BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: table base pointers must be 16-byte aligned");
+  h->t = *t;
+  h->bound = true;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_set_hyper(bprx_handle *h, float lr, float reg) {
+  if (!h) return BPRX_E_INVALID;
+  h->cfg.lr = lr;
+  h->cfg.reg = reg;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_set_adam_step(bprx_handle *h, int64_t it) {
+  if (!h || it < 0) return BPRX_E_INVALID;
+  h->adam_t = it;
+  return BPRX_OK;
+}
+
+extern "C" int64_t bprx_get_adam_step(const bprx_handle *h) { return h ? h->adam_t : -1; }
+
+static int check_ready(bprx_handle *h, int64_t B) {
+  if (!h) return BPRX_E_INVALID;
+  if (!h->bound) BPRX_FAIL(h, BPRX_E_STATE, "tables not bound (call bprx_bind_tables first)");
+  if (B < 0 || B > h->cfg.max_batch) BPRX_FAIL(h, BPRX_E_INVALID, "B=%lld outside [0, max_batch=%lld]", (long long)B, (long long)h->cfg.max_batch);
+  return BPRX_OK;
+}
+
+extern "C" int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32_t *item, int64_t B, float *x, void *stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if (B == 0) return BPRX_OK;
+  if (!user || !item || !x) BPRX_FAIL(h, BPRX_E_INVALID, "score_pairs: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->cfg.model == BPRX_MODEL_VBPR) {
+    if ((rc = bprx_launch_cast_Et(h, s))) return rc;
+    if ((rc = bprx_launch_proj_fwd(h, item, B, h->Ppair, s))) return rc;   // one projection row per pair
+    return bprx_launch_score(h, user, item, B, h->Ppair, 1, x, s);
+  }
+  return bprx_launch_score(h, user, item, B, nullptr, 0, x, s);
+}
+
+extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, void *stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if (B == 0) BPRX_FAIL(h, BPRX_E_INVALID, "step: empty batch");
+  if (!user || !pos || !neg) BPRX_FAIL(h, BPRX_E_INVALID, "step: null index pointer");
+  if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  BPRX_HIP(h, hipMemsetAsync(h->loss_acc, 0, 4 * sizeof(double), s));
+  if (vb) {
+    if ((rc = bprx_launch_cast_Et(h, s))) return rc;
+    if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
+  }
+  if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
+  if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;                              // dE|dBp = F^T W
+  // sparse tables are final now: apply their optimizer (does not depend on the dense all-reduce)
+  float lr_t = h->cfg.lr;
+  if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
+    h->adam_t += 1;
+    float t = (float)h->adam_t;
+    lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
+  }
+  if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, s))) return rc;
+  h->pending_B = B;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_dense_grad(bprx_handle *h, float **ptr, int64_t *count) {
+  if (!h || !ptr || !count) return BPRX_E_INVALID;
+  *ptr = h->dEp;
+  *count = h->cfg.model == BPRX_MODEL_VBPR ? (int64_t)h->cfg.feat_dim * (h->cfg.embed_d + 1) : 0;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (!h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_end without step_begin");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  float lr_t = h->cfg.lr;
+  if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
+    float t = (float)h->adam_t;
+    lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
+  }
+  int64_t B = h->pending_B;
+  h->pending_B = 0;
+  if (h->cfg.model == BPRX_MODEL_VBPR && (rc = bprx_launch_dense_update(h, lr_t, s))) return rc;
+  if (loss_out && (rc = bprx_launch_loss_reduce(h, B, loss_out, s))) return rc;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
+                         float *loss_out, void *stream) {
+  int rc = bprx_step_begin(h, user, pos, neg, B, stream);
+  if (rc) return rc;
+  return bprx_step_end(h, loss_out, stream);
+}
+
+extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream) {
+  int rc = check_ready(h, 0);
+  if (rc) return rc;
+  if (u0 < 0 || u1 > h->cfg.num_users || u0 > u1 || !out) BPRX_FAIL(h, BPRX_E_INVALID, "score_block: bad user range [%d,%d)", u0, u1);
+  if (u0 == u1) return BPRX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->cfg.model == BPRX_MODEL_VBPR) {
+    if ((rc = bprx_launch_cast_Et(h, s))) return rc;
+    if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;
+  }
+  return bprx_launch_score_block(h, u0, u1, out, s);
+}
+
+extern "C" int bprx_sync_check(bprx_handle *h, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t flag = 0;
+  BPRX_HIP(h, hipMemcpyAsync(&flag, h->errflag, sizeof(flag), hipMemcpyDeviceToHost, s));
+  BPRX_HIP(h, hipStreamSynchronize(s));
+  if (flag) {
+    BPRX_HIP(h, hipMemsetAsync(h->errflag, 0, sizeof(flag), s));
+    BPRX_FAIL(h, BPRX_E_RANGE, "a user/item index was out of range (code %d); it was clamped, results are invalid", flag);
+  }
+  return BPRX_OK;
+}

@@ -1,0 +1,67 @@
+// bprx_internal.h -- private state of libbprx.so (C ABI: include/bprx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "bprx.h"
+
+struct bprx_handle {
+  bprx_config cfg;
+  bprx_tables t;
+  bool bound;
+  int64_t adam_t;          // optimizer.iterations
+  char err[512];
+
+  // ---- scratch owned by the handle (device) ----
+  float *dGu, *dGi, *dBi, *dTu;   // dense fp32 gradient staging, same shapes as the tables; all-zero between steps
+  uint32_t *flagU, *flagI;        // "row touched this step" marks (sgd claim)
+  float *lossb;                   // [max_batch] per-triplet loss (data + per-occurrence regularisation)
+  double *loss_acc;               // [4] scalars: [0] sum(lossb) [1] ||E||^2+||Bp||^2
+  int32_t *errflag;               // device-side deferred error (index out of range)
+  // VBPR projection state
+  int PS;                         // padded row stride of P/W/Et: 16*ceil((d+1)/16)
+  float *P;                       // [I][PS]  item projections f_i.[E|Bp]
+  float *W;                       // [I][PS]  sum_b +-g_b*[theta_u|1] per item; all-zero between steps
+  float *Ppair;                   // [max_batch][PS] projections for bprx_score_pairs
+  void *Et;                       // bf16 [PS][D]: [E|Bp|0]^T, refreshed every step
+  float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
+  float *part;                    // [SK][D][PS] split-K slabs of the backward projection
+  int SK;
+  int64_t pending_B;              // B of the step between _begin and _end (0 = none)
+};
+
+#define BPRX_FAIL(h, code, ...)                                   \
+  do {                                                            \
+    snprintf((h)->err, sizeof((h)->err), __VA_ARGS__);            \
+    return (code);                                                \
+  } while (0)
+
+#define BPRX_HIP(h, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess) BPRX_FAIL(h, BPRX_E_HIP, "%s: %s", #call, hipGetErrorString(e__));      \
+  } while (0)
+
+#define BPRX_LAUNCH_CHECK(h, name)                                                                 \
+  do {                                                                                             \
+    hipError_t e__ = hipGetLastError();                                                            \
+    if (e__ != hipSuccess) BPRX_FAIL(h, BPRX_E_HIP, "launch %s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- launchers implemented in the kernel translation units ----
+// sparse part (bprx_sparse.hip)
+int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_t B, const float *Prow,
+                      int p_by_pair, float *x, hipStream_t s);
+int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
+                             hipStream_t s);
+int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
+                      float lr_t, hipStream_t s);
+int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s);
+int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStream_t s);
+int bprx_launch_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);
+// projection part (bprx_proj.hip)
+int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s);
+int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s);
+int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s);

@@ -1,0 +1,318 @@
+// bprx_proj.hip -- gfx950 kernels for VBPR's visual projection, item-centric:
+//   forward   P[t, 0:d] = f_t . E ,  P[t, d] = f_t . Bp          (VBPR.py:83-84, one row per item, not per triplet)
+//   backward  dE = sum_t f_t^T W[t, 0:d] , dBp = sum_t f_t W[t,d] (the dense gradients of VBPR.py:141)
+// with W[t] = sum over the batch of +-g_b*[theta_u | 1] (bprx_sparse.hip).  Both products read every
+// feature row exactly once per step; they are HBM-bound (8 KB bf16 row vs 655 KFLOP), so the layout goal is
+// full-width coalesced row streaming with enough bytes in flight, and MFMA only has to keep up:
+//   bf16 path: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Bp rides along as column d of [E|Bp|0] (N padded
+//              to a multiple of 16).
+//   fp32 path: exact reference-precision path for small configs (fp64 accumulate on the vector ALU).
+#include "bprx_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ uint16_t f2bf(float x) {   // round-to-nearest-even; inputs are finite
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// Et[n][k] (bf16, [PS][D]) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.   One thread per (n, k).
+__global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, const float *__restrict__ Bp,
+                                                 uint16_t *__restrict__ Et, int D, int d, int PS) {
+  const int kk = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (kk >= D) return;
+  float v = n < d ? E[(size_t)kk * d + n] : (n == d ? Bp[kk] : 0.f);
+  Et[(size_t)n * D + kk] = f2bf(v);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward, bf16.  Workgroup = 4 waves; wave w owns MT tiles of 16 rows; all NT column tiles stay in registers.
+// A (feature rows) goes HBM -> VGPR directly in MFMA operand order (lane: row l&15, 16 B at k = 8*(l>>4));
+// B ([E|Bp]^T chunk, shared by the 4 waves and re-read from L2 by every workgroup) is staged through LDS.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int KC = 128;          // k-chunk staged per barrier pair
+constexpr int BS_STRIDE = KC + 8;  // bf16 elements; 272-B rows keep ds_read_b128 nearly conflict-free
+
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                       int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                       float *__restrict__ P, int PS, int32_t *errflag) {
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * BS_STRIDE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;                      // padding lanes re-read the last row; never stored
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < D; k0 += KC) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NT * 16 * (KC / 8); idx += 256) {
+      const int n = idx / (KC / 8), kk = (idx % (KC / 8)) * 8;
+      *reinterpret_cast<uint4 *>(&Bs[n * BS_STRIDE + kk]) = *reinterpret_cast<const uint4 *>(&Et[(size_t)n * D + k0 + kk]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 32) {
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k0 + ks);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * BS_STRIDE + ks + q * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4)*4 + reg
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + mt * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, bf16.  out[m, n] = sum_t F[t, m] * W[t, n]: both operands are stored t-major but the MFMA wants
+// the reduction index contiguous per lane, so 32-item tiles of F (128 columns) and W go through LDS and are
+// read back with the hardware transpose read ds_read_b64_tr_b16.  grid = (D/128 column ranges, SK item splits);
+// every workgroup writes its fp32 partial [128, PS] slab with plain stores; k_reduce_parts sums the SK slabs in a
+// fixed order (bit-reproducible, no float atomics).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BT = 32;                 // items per tile = one MFMA k-step
+constexpr int FS_STRIDE = 128 + 16;    // 288-B rows: 8 rows x 32 B cover the 64 banks exactly once
+template <int NT>
+struct WsStride {                      // bf16 elements; (bytes/4) % 64 == 8
+  static constexpr int raw = NT * 16;
+  static constexpr int value = ((raw * 2 + 255 - 32) / 256) * 128 + 16;
+};
+
+__device__ __forceinline__ bf16x4 lds_tr16(const uint16_t *p) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_proj_bwd_bf16(const uint16_t *__restrict__ F, int nrows, int D,
+                                                       const float *__restrict__ W, int PS, float *__restrict__ part,
+                                                       int rows_per_split) {
+  constexpr int WS = WsStride<NT>::value;
+  __shared__ __attribute__((aligned(16))) uint16_t Fs[BT * FS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[BT * WS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+  const int m0 = blockIdx.x * 128;
+  const int tbeg = blockIdx.y * rows_per_split;
+  int tend = tbeg + rows_per_split;
+  if (tend > nrows) tend = nrows;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t0 = tbeg; t0 < tend; t0 += BT) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BT * 16; idx += 256) {       // F tile: 32 rows x 16 chunks of 16 B
+      const int tr = idx >> 4, ch = idx & 15, t = t0 + tr;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (t < tend) v = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
+      *reinterpret_cast<uint4 *>(&Fs[tr * FS_STRIDE + ch * 8]) = v;
+    }
+    for (int idx = threadIdx.x; idx < BT * NT * 4; idx += 256) {   // W tile: fp32 -> bf16
+      const int tr = idx / (NT * 4), c4 = idx % (NT * 4), t = t0 + tr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < tend) v = *reinterpret_cast<const float4 *>(W + (size_t)t * PS + c4 * 4);
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+      pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+      *reinterpret_cast<uint2 *>(&Ws[tr * WS + c4 * 4]) = pk;
+    }
+    __syncthreads();
+    // lane 16g + 4qq + p supplies row (8g + qq [+4]) , columns 4p..4p+3 of a 16-column block and receives
+    // column i16 of rows 8g..8g+3 [+4]: exactly the 16x16x32 operand order  X[row/col i16][k = 8g + j].
+    bf16x8 a[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int col = (w * 2 + mt) * 16 + 4 * p;
+      bf16x4 lo = lds_tr16(&Fs[(8 * g + qq) * FS_STRIDE + col]);
+      bf16x4 hi = lds_tr16(&Fs[(8 * g + qq + 4) * FS_STRIDE + col]);
+      a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + 4 * p;
+      bf16x4 lo = lds_tr16(&Ws[(8 * g + qq) * WS + col]);
+      bf16x4 hi = lds_tr16(&Ws[(8 * g + qq + 4) * WS + col]);
+      const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+    }
+  }
+  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = (w * 2 + mt) * 16 + g * 4 + reg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
+    }
+}
+
+// dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
+__global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
+                                                      float *__restrict__ dEp) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)D * PS) return;
+  const int kk = (int)(e / PS), n = (int)(e % PS);
+  if (n > d) return;
+  float s = 0.f;
+  for (int sidx = 0; sidx < SK; ++sidx) s += part[(size_t)sidx * D * PS + e];
+  if (n < d) dEp[(size_t)kk * d + n] = s;
+  else dEp[(size_t)D * d + kk] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 feature path (small, reference-precision configs): fp64 accumulate on the vector ALU.
+// ------------------------------------------------------------------------------------------------------------
+// one wave per row; lane n owns output columns n, n+64, ...; F[t][k] is a wave-wide broadcast, E rows are coalesced.
+__global__ __launch_bounds__(256) void k_proj_fwd_f32(const float *__restrict__ F, const int32_t *__restrict__ rows,
+                                                      int nrows, int nitems, int D, const float *__restrict__ E,
+                                                      const float *__restrict__ Bp, int d, float *__restrict__ P, int PS,
+                                                      int32_t *errflag) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= nrows) return;
+  int item = rows ? rows[t] : t;
+  if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+  const float *f = F + (size_t)item * D;
+  for (int n = lane; n <= d; n += 64) {
+    double acc = 0.0;
+    if (n < d) for (int kk = 0; kk < D; ++kk) acc += (double)f[kk] * (double)E[(size_t)kk * d + n];
+    else for (int kk = 0; kk < D; ++kk) acc += (double)f[kk] * (double)Bp[kk];
+    P[(size_t)t * PS + n] = (float)acc;
+  }
+}
+
+// one thread per output (k, n), n <= d; W rows are coalesced over n, F[t][k] is a broadcast.
+__global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ F, int nrows, int D,
+                                                      const float *__restrict__ W, int d, int PS, float *__restrict__ dEp) {
+  const int kk = blockIdx.x;
+  for (int n = threadIdx.x; n <= d; n += 256) {
+    double acc = 0.0;
+    for (int t = 0; t < nrows; ++t) acc += (double)F[(size_t)t * D + kk] * (double)W[(size_t)t * PS + n];
+    if (n < d) dEp[(size_t)kk * d + n] = (float)acc;
+    else dEp[(size_t)D * d + kk] = (float)acc;
+  }
+}
+
+template <int NT>
+int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
+  constexpr int MT = NT <= 9 ? 2 : 1;
+  const int rows_per_wg = 4 * MT * 16;
+  dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
+  hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MT>), grid, dim3(256), 0, s, (const uint16_t *)h->t.F, rows, (int)nrows,
+                     h->cfg.num_items, h->cfg.feat_dim, (const uint16_t *)h->Et, Pout, h->PS, h->errflag);
+  return 0;
+}
+
+template <int NT>
+int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
+  const int D = h->cfg.feat_dim, I = h->cfg.num_items;
+  int rps = (I + h->SK - 1) / h->SK;
+  rps = (rps + BT - 1) / BT * BT;
+  dim3 grid(D / 128, h->SK);
+  hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, h->W, h->PS, h->part, rps);
+  return 0;
+}
+
+#define NT_SWITCH(NT, CALL)            \
+  switch (NT) {                        \
+    case 1: CALL(1); break;            \
+    case 2: CALL(2); break;            \
+    case 3: CALL(3); break;            \
+    case 4: CALL(4); break;            \
+    case 5: CALL(5); break;            \
+    case 6: CALL(6); break;            \
+    case 7: CALL(7); break;            \
+    case 8: CALL(8); break;            \
+    case 9: CALL(9); break;            \
+    case 10: CALL(10); break;          \
+    case 11: CALL(11); break;          \
+    case 12: CALL(12); break;          \
+    case 13: CALL(13); break;          \
+    case 14: CALL(14); break;          \
+    case 15: CALL(15); break;          \
+    case 16: CALL(16); break;          \
+    default: CALL(17); break;          \
+  }
+
+}  // namespace
+
+int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
+  if (h->cfg.feat_dtype != BPRX_F_BF16) return BPRX_OK;
+  const int D = h->cfg.feat_dim;
+  dim3 grid((D + 255) / 256, h->PS);
+  hipLaunchKernelGGL(k_cast_Et, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint16_t *)h->Et, D, h->cfg.embed_d, h->PS);
+  BPRX_LAUNCH_CHECK(h, "k_cast_Et");
+  return BPRX_OK;
+}
+
+int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
+  if (nrows <= 0) return BPRX_OK;
+  if (h->cfg.feat_dtype == BPRX_F_BF16) {
+    const int NT = h->PS / 16;
+#define CALL(N) launch_fwd_nt<N>(h, rows, nrows, Pout, s)
+    NT_SWITCH(NT, CALL)
+#undef CALL
+    BPRX_LAUNCH_CHECK(h, "k_proj_fwd_bf16");
+  } else {
+    dim3 grid((unsigned)((nrows + 3) / 4));
+    hipLaunchKernelGGL(k_proj_fwd_f32, grid, dim3(256), 0, s, (const float *)h->t.F, rows, (int)nrows, h->cfg.num_items,
+                       h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
+    BPRX_LAUNCH_CHECK(h, "k_proj_fwd_f32");
+  }
+  return BPRX_OK;
+}
+
+int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s) {
+  const int D = h->cfg.feat_dim, d = h->cfg.embed_d, I = h->cfg.num_items;
+  if (h->cfg.feat_dtype == BPRX_F_BF16) {
+    const int NT = h->PS / 16;
+#define CALL(N) launch_bwd_nt<N>(h, s)
+    NT_SWITCH(NT, CALL)
+#undef CALL
+    BPRX_LAUNCH_CHECK(h, "k_proj_bwd_bf16");
+    const size_t n = (size_t)D * h->PS;
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK, D, d, h->PS, h->dEp);
+    BPRX_LAUNCH_CHECK(h, "k_reduce_parts");
+  } else {
+    hipLaunchKernelGGL(k_proj_bwd_f32, dim3(D), dim3(256), 0, s, (const float *)h->t.F, I, D, h->W, d, h->PS, h->dEp);
+    BPRX_LAUNCH_CHECK(h, "k_proj_bwd_f32");
+  }
+  return BPRX_OK;
+}

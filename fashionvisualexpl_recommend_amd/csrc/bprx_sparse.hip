@@ -1,0 +1,461 @@
+// bprx_sparse.hip -- gfx950 kernels for the factor-table half of the BPR step:
+//   k_score         Model.call                         BPRMF.py:55-76 / VBPR.py:59-86
+//   k_triplet_grad  forward + analytic gradients       BPRMF.py:87-122 / VBPR.py:99-141 (GradientTape restated)
+//   k_apply_sgd / k_adam_sparse / k_dense_update       optimizer.apply_gradients  BPRMF.py:123 / VBPR.py:142
+//   k_score_block   predict_all                        BPRMF.py:78-85 / VBPR.py:88-97
+//
+// Layout: a group of G lanes (G = 8..64, a power of two, G*4 >= row length where possible) owns one
+// (user, item[, item]) tuple; each lane moves 16 B of a factor row per load, so a row is one fully
+// coalesced segment; dot products are reduced with wavefront shuffles inside the group (64-wide waves,
+// groups never straddle a wave).  Everything is HBM-/L2-bound gather-scatter: no LDS, no MFMA.
+//
+// Batch-synchronous semantics: k_triplet_grad reads only pre-update values and ADDS per-occurrence
+// gradients into zero-initialised dense staging tables (fp32 global atomics, one 16-B-per-lane row
+// segment per wave instruction); the optimizer kernels then apply each touched row exactly once and
+// re-zero the staging rows.
+#include "bprx_internal.h"
+
+namespace {
+
+struct SparseArgs {
+  const float *Gu, *Gi, *Bi, *Tu;
+  float *dGu, *dGi, *dBi, *dTu;
+  uint32_t *flagU, *flagI;
+  const float *P;   // [*, PS] projections (VBPR) or nullptr
+  float *W;         // [I, PS]
+  float *lossb;
+  int32_t *errflag;
+  int U, I, k, d, PS;
+  float reg;
+};
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+
+__device__ __forceinline__ int clamp_idx(int v, int n, int32_t *errflag, int code) {
+  if ((unsigned)v >= (unsigned)n) {
+    *errflag = code;
+    return v < 0 ? 0 : n - 1;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// x_ui = Bi[i] + <Gu[u],Gi[i]> (+ <Tu[u],P[0:d]> + P[d])
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_score(SparseArgs a, const int32_t *__restrict__ user,
+                                               const int32_t *__restrict__ item, int64_t B, int p_by_pair,
+                                               float *__restrict__ x) {
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (b >= B) return;
+  const int u = clamp_idx(user[b], a.U, a.errflag, 1), i = clamp_idx(item[b], a.I, a.errflag, 2);
+  const float *gu = a.Gu + (size_t)u * a.k, *gi = a.Gi + (size_t)i * a.k;
+  float s = 0.f;
+  if (VEC) {
+    for (int c = lane * 4; c < a.k; c += G * 4) {
+      float4 p = ld4(gu + c), q = ld4(gi + c);
+      s += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+    }
+  } else {
+    for (int c = lane; c < a.k; c += G) s += gu[c] * gi[c];
+  }
+  s = group_sum<G>(s);
+  float xv = a.Bi[i] + s;
+  if (a.d > 0) {
+    const float *tu = a.Tu + (size_t)u * a.d;
+    const float *P = a.P + (size_t)(p_by_pair ? b : i) * a.PS;
+    float t = 0.f;
+    if (VEC) {
+      for (int c = lane * 4; c < a.d; c += G * 4) {
+        float4 p = ld4(tu + c), q = ld4(P + c);
+        t += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+      }
+    } else {
+      for (int c = lane; c < a.d; c += G) t += tu[c] * P[c];
+    }
+    t = group_sum<G>(t);
+    xv = xv + t + P[a.d];
+  }
+  if (lane == 0) x[b] = xv;
+}
+
+__device__ __forceinline__ void atomic_add4(float *p, float4 v) {
+  atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+// One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
+                                                      const int32_t *__restrict__ pos,
+                                                      const int32_t *__restrict__ neg, int64_t B) {
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (b >= B) return;
+  const int u = clamp_idx(user[b], a.U, a.errflag, 1);
+  const int i = clamp_idx(pos[b], a.I, a.errflag, 2), j = clamp_idx(neg[b], a.I, a.errflag, 3);
+  const int k = a.k, d = a.d;
+  const float *gu = a.Gu + (size_t)u * k, *gi = a.Gi + (size_t)i * k, *gj = a.Gi + (size_t)j * k;
+  const float *tu = d ? a.Tu + (size_t)u * d : nullptr;
+  const float *Pi = d ? a.P + (size_t)i * a.PS : nullptr, *Pj = d ? a.P + (size_t)j * a.PS : nullptr;
+
+  // ---- forward: the un-differenced per-item scores of the reference (BPRMF.py:101-102) ----
+  float si = 0.f, sj = 0.f, nrm = 0.f;   // <gu,gi>, <gu,gj>, |gu|^2+|gi|^2+|gj|^2 (+|tu|^2)
+  if (VEC) {
+    for (int c = lane * 4; c < k; c += G * 4) {
+      float4 p = ld4(gu + c), q = ld4(gi + c), r = ld4(gj + c);
+      si += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+      sj += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
+      nrm += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w + q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w +
+             r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+    }
+  } else {
+    for (int c = lane; c < k; c += G) {
+      float p = gu[c], q = gi[c], r = gj[c];
+      si += p * q; sj += p * r; nrm += p * p + q * q + r * r;
+    }
+  }
+  float ti = 0.f, tj = 0.f;
+  if (d) {
+    if (VEC) {
+      for (int c = lane * 4; c < d; c += G * 4) {
+        float4 p = ld4(tu + c), q = ld4(Pi + c), r = ld4(Pj + c);
+        ti += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+        tj += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
+        nrm += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+      }
+    } else {
+      for (int c = lane; c < d; c += G) {
+        float p = tu[c];
+        ti += p * Pi[c]; tj += p * Pj[c]; nrm += p * p;
+      }
+    }
+  }
+  si = group_sum<G>(si); sj = group_sum<G>(sj); nrm = group_sum<G>(nrm);
+  const float bi = a.Bi[i], bj = a.Bi[j];
+  float xp = bi + si, xn = bj + sj;
+  if (d) {
+    ti = group_sum<G>(ti); tj = group_sum<G>(tj);
+    xp = xp + ti + Pi[d];
+    xn = xn + tj + Pj[d];
+  }
+  const float diff = xp - xn;
+  const bool inr = (diff >= -80.0f) && (diff <= 1e8f);                 // tf.clip_by_value gradient mask
+  const float cl = fminf(fmaxf(diff, -80.0f), 1e8f);
+  const float z = -cl;                                                 // softplus(z), stable form
+  const float sp = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
+  const float g = inr ? -1.0f / (1.0f + expf(diff)) : 0.f;            // -sigmoid(-diff)
+  const float reg = a.reg, r2 = 2.f * reg;
+  if (lane == 0) {
+    a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
+    atomicAdd(a.dBi + i, g + r2 * bi);
+    atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
+    a.flagU[u] = 1u; a.flagI[i] = 1u; a.flagI[j] = 1u;
+  }
+  // ---- backward: per-occurrence gradients from the same pre-update rows ----
+  float *au = a.dGu + (size_t)u * k, *ai = a.dGi + (size_t)i * k, *aj = a.dGi + (size_t)j * k;
+  if (VEC) {
+    for (int c = lane * 4; c < k; c += G * 4) {
+      float4 p = ld4(gu + c), q = ld4(gi + c), r = ld4(gj + c);
+      atomic_add4(au + c, make_float4(g * (q.x - r.x) + r2 * p.x, g * (q.y - r.y) + r2 * p.y,
+                                      g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w));
+      atomic_add4(ai + c, make_float4(g * p.x + r2 * q.x, g * p.y + r2 * q.y, g * p.z + r2 * q.z, g * p.w + r2 * q.w));
+      atomic_add4(aj + c, make_float4(-g * p.x + r2 * r.x, -g * p.y + r2 * r.y, -g * p.z + r2 * r.z, -g * p.w + r2 * r.w));
+    }
+  } else {
+    for (int c = lane; c < k; c += G) {
+      float p = gu[c], q = gi[c], r = gj[c];
+      atomicAdd(au + c, g * (q - r) + r2 * p);
+      atomicAdd(ai + c, g * p + r2 * q);
+      atomicAdd(aj + c, -g * p + r2 * r);
+    }
+  }
+  if (d) {
+    float *at = a.dTu + (size_t)u * d;
+    float *wi = a.W + (size_t)i * a.PS, *wj = a.W + (size_t)j * a.PS;
+    if (VEC) {
+      for (int c = lane * 4; c < d; c += G * 4) {
+        float4 p = ld4(tu + c), q = ld4(Pi + c), r = ld4(Pj + c);
+        atomic_add4(at + c, make_float4(g * (q.x - r.x) + r2 * p.x, g * (q.y - r.y) + r2 * p.y,
+                                        g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w));
+        float4 gp = make_float4(g * p.x, g * p.y, g * p.z, g * p.w);
+        atomic_add4(wi + c, gp);
+        atomic_add4(wj + c, make_float4(-gp.x, -gp.y, -gp.z, -gp.w));
+      }
+    } else {
+      for (int c = lane; c < d; c += G) {
+        float p = tu[c];
+        atomicAdd(at + c, g * (Pi[c] - Pj[c]) + r2 * p);
+        atomicAdd(wi + c, g * p);
+        atomicAdd(wj + c, -g * p);
+      }
+    }
+    if (lane == 0) { atomicAdd(wi + d, g); atomicAdd(wj + d, -g); }     // the Bp column of [theta|1]
+  }
+}
+
+// sgd: one group per occurrence; the first to claim a touched row applies  p -= lr*dG  and re-zeroes dG.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *Bi, float *Tu, SparseArgs a,
+                                                   const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
+                                                   const int32_t *__restrict__ neg, int64_t B, float lr) {
+  const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (job >= 3 * B) return;
+  const int kind = (int)(job / B);
+  const int64_t b = job - (int64_t)kind * B;
+  int row;
+  uint32_t *flag;
+  if (kind == 0) { row = clamp_idx(user[b], a.U, a.errflag, 1); flag = a.flagU + row; }
+  else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; }
+  unsigned claimed = 0;
+  if (lane == 0) claimed = atomicExch(flag, 0u);
+  claimed = __shfl(claimed, 0, G);
+  if (!claimed) return;
+  float *p0 = kind == 0 ? Gu : Gi, *g0 = kind == 0 ? a.dGu : a.dGi;
+  const int k = a.k;
+  float *p = p0 + (size_t)row * k, *gr = g0 + (size_t)row * k;
+  if (VEC) {
+    for (int c = lane * 4; c < k; c += G * 4) {
+      float4 v = ld4(p + c), gg = ld4(gr + c);
+      v.x -= lr * gg.x; v.y -= lr * gg.y; v.z -= lr * gg.z; v.w -= lr * gg.w;
+      *reinterpret_cast<float4 *>(p + c) = v;
+      *reinterpret_cast<float4 *>(gr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    for (int c = lane; c < k; c += G) { p[c] -= lr * gr[c]; gr[c] = 0.f; }
+  }
+  if (kind == 0 && a.d) {
+    const int d = a.d;
+    float *t = Tu + (size_t)row * d, *gt = a.dTu + (size_t)row * d;
+    if (VEC) {
+      for (int c = lane * 4; c < d; c += G * 4) {
+        float4 v = ld4(t + c), gg = ld4(gt + c);
+        v.x -= lr * gg.x; v.y -= lr * gg.y; v.z -= lr * gg.z; v.w -= lr * gg.w;
+        *reinterpret_cast<float4 *>(t + c) = v;
+        *reinterpret_cast<float4 *>(gt + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      for (int c = lane; c < d; c += G) { t[c] -= lr * gt[c]; gt[c] = 0.f; }
+    }
+  }
+  if (kind != 0 && lane == 0) { Bi[row] -= lr * a.dBi[row]; a.dBi[row] = 0.f; }
+}
+
+// adam_tf23, sparse-variable rule applied to the WHOLE table (TF-2.3 Keras Adam is not lazy):
+//   m = m*b1 + g*(1-b1); v = v*b2 + g*g*(1-b2); var -= lr_t*m/(sqrt(v)+eps)     (g == 0 on untouched rows)
+__global__ __launch_bounds__(256) void k_adam_sparse(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
+                                                     float *__restrict__ g, size_t n, float b1, float b2, float lr_t, float eps) {
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    float gg = g[e];
+    float mt = m[e] * b1 + gg * omb1;
+    float vt = v[e] * b2 + (gg * gg) * omb2;
+    m[e] = mt; v[e] = vt;
+    p[e] = p[e] - lr_t * mt / (sqrtf(vt) + eps);
+    g[e] = 0.f;
+  }
+}
+
+__global__ void k_clear_flags(uint32_t *f, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) f[e] = 0u;
+}
+
+// Dense shared parameters E [D,d] and Bp [D]: grad = dEp (+ all-reduced) + 2*reg*param, then sgd or the
+// dense ApplyAdam rule  m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)   (VBPR.py:142).
+// Also accumulates ||E||^2+||Bp||^2 (pre-update) for the loss (VBPR.py:127).
+__global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, float *__restrict__ Bp, float *mE, float *vE,
+                                                      float *mBp, float *vBp, const float *__restrict__ dEp, size_t nE,
+                                                      size_t nB, int adam, float lr_t, float reg, float b1, float b2,
+                                                      float eps, double *loss_acc) {
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  double sq = 0.0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nE + nB; e += (size_t)gridDim.x * blockDim.x) {
+    float *p = e < nE ? E + e : Bp + (e - nE);
+    float pv = *p;
+    sq += (double)pv * (double)pv;
+    float gg = dEp[e] + 2.f * reg * pv;
+    if (adam) {
+      float *m = e < nE ? mE + e : mBp + (e - nE), *v = e < nE ? vE + e : vBp + (e - nE);
+      float mt = *m + (gg - *m) * omb1;
+      float vt = *v + (gg * gg - *v) * omb2;
+      *m = mt; *v = vt;
+      *p = pv - lr_t * mt / (sqrtf(vt) + eps);
+    } else {
+      *p = pv - lr_t * gg;
+    }
+  }
+  // block reduction of sq -> one double atomic per block (a few hundred per step)
+  __shared__ double red[256];
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss_acc + 1, red[0]);
+}
+
+// loss = sum_b lossb[b] + reg*(||E||^2+||Bp||^2); fixed summation order (one block), double accumulation.
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ lossb, int64_t B, double *loss_acc,
+                                                      float reg, float *__restrict__ out) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) s += (double)lossb[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *out = (float)(red[0] + (double)reg * loss_acc[1]);
+    loss_acc[1] = 0.0;
+  }
+}
+
+// predict_all rows [u0,u1): out[u-u0][i] = Bi[i] + <Gu[u],Gi[i]> (+ <Tu[u],P_i[0:d]> + P_i[d]).
+// One thread per (u, i); a 16x16 tile of users x items per block keeps both row sets L1-resident.
+__global__ __launch_bounds__(256) void k_score_block(SparseArgs a, int u0, int u1, float *__restrict__ out) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ub = u0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= a.I || ub >= u1) return;
+  const float *gu = a.Gu + (size_t)ub * a.k, *gi = a.Gi + (size_t)i * a.k;
+  float s = 0.f;
+  for (int c = 0; c < a.k; ++c) s += gu[c] * gi[c];
+  float xv = a.Bi[i] + s;
+  if (a.d) {
+    const float *tu = a.Tu + (size_t)ub * a.d, *P = a.P + (size_t)i * a.PS;
+    float t = 0.f;
+    for (int c = 0; c < a.d; ++c) t += tu[c] * P[c];
+    xv = xv + t + P[a.d];
+  }
+  out[(size_t)(ub - u0) * a.I + i] = xv;
+}
+
+SparseArgs make_args(bprx_handle *h, const float *P) {
+  SparseArgs a;
+  a.Gu = h->t.Gu; a.Gi = h->t.Gi; a.Bi = h->t.Bi; a.Tu = h->t.Tu;
+  a.dGu = h->dGu; a.dGi = h->dGi; a.dBi = h->dBi; a.dTu = h->dTu;
+  a.flagU = h->flagU; a.flagI = h->flagI;
+  a.P = P; a.W = h->W; a.lossb = h->lossb; a.errflag = h->errflag;
+  a.U = h->cfg.num_users; a.I = h->cfg.num_items; a.k = h->cfg.embed_k; a.d = h->cfg.embed_d; a.PS = h->PS;
+  a.reg = h->cfg.reg;
+  return a;
+}
+
+// group width: smallest power of two G in [8,64] with G*4 >= max(k,d)
+int pick_group(int k, int d, bool vec) {
+  int need = k > d ? k : d;
+  int per = vec ? 4 : 1;
+  int G = 8;
+  while (G < 64 && G * per < need) G <<= 1;
+  return G;
+}
+
+#define DISPATCH_G(G, VEC, KERNEL, grid, s, ...)                                               \
+  do {                                                                                         \
+    if (VEC) {                                                                                 \
+      switch (G) {                                                                             \
+        case 8: hipLaunchKernelGGL((KERNEL<8, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;   \
+        case 16: hipLaunchKernelGGL((KERNEL<16, true>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+        case 32: hipLaunchKernelGGL((KERNEL<32, true>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((KERNEL<64, true>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+      }                                                                                        \
+    } else {                                                                                   \
+      switch (G) {                                                                             \
+        case 8: hipLaunchKernelGGL((KERNEL<8, false>), grid, dim3(256), 0, s, __VA_ARGS__); break;   \
+        case 16: hipLaunchKernelGGL((KERNEL<16, false>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+        case 32: hipLaunchKernelGGL((KERNEL<32, false>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((KERNEL<64, false>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+      }                                                                                        \
+    }                                                                                          \
+  } while (0)
+
+inline bool vec_ok(const bprx_handle *h) {
+  return h->cfg.embed_k % 4 == 0 && h->cfg.embed_d % 4 == 0;   // PS is always a multiple of 16
+}
+
+inline dim3 grid_for(int64_t groups, int G) {
+  int64_t threads = groups * G;
+  return dim3((unsigned)((threads + 255) / 256));
+}
+
+}  // namespace
+
+int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_t B, const float *Prow, int p_by_pair,
+                      float *x, hipStream_t s) {
+  SparseArgs a = make_args(h, h->cfg.embed_d ? (p_by_pair ? Prow : h->P) : nullptr);
+  const bool vec = vec_ok(h);
+  const int G = pick_group(a.k, a.d, vec);
+  DISPATCH_G(G, vec, k_score, grid_for(B, G), s, a, u, i, B, p_by_pair, x);
+  BPRX_LAUNCH_CHECK(h, "k_score");
+  return BPRX_OK;
+}
+
+int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
+  SparseArgs a = make_args(h, h->P);
+  const bool vec = vec_ok(h);
+  const int G = pick_group(a.k, a.d, vec);
+  if (a.d) BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
+  DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
+  BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
+  return BPRX_OK;
+}
+
+int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t, hipStream_t s) {
+  SparseArgs a = make_args(h, nullptr);
+  const size_t U = a.U, I = a.I, k = a.k, d = a.d;
+  if (h->cfg.optimizer == BPRX_OPT_SGD) {
+    const bool vec = vec_ok(h);
+    const int G = pick_group(a.k, a.d, vec);
+    DISPATCH_G(G, vec, k_apply_sgd, grid_for(3 * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B, lr_t);
+    BPRX_LAUNCH_CHECK(h, "k_apply_sgd");
+    return BPRX_OK;
+  }
+  const float b1 = h->cfg.beta1, b2 = h->cfg.beta2, eps = h->cfg.epsilon;
+  auto sweep = [&](float *p, float *m, float *v, float *g, size_t n) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adam_sparse, dim3(blocks), dim3(256), 0, s, p, m, v, g, n, b1, b2, lr_t, eps);
+  };
+  sweep(h->t.Bi, h->t.m_Bi, h->t.v_Bi, h->dBi, I);              // params order of BPRMF.py:117-121 / VBPR.py:132-139
+  sweep(h->t.Gu, h->t.m_Gu, h->t.v_Gu, h->dGu, U * k);
+  sweep(h->t.Gi, h->t.m_Gi, h->t.v_Gi, h->dGi, I * k);
+  if (d) sweep(h->t.Tu, h->t.m_Tu, h->t.v_Tu, h->dTu, U * d);
+  // the sgd claim marks are unused by adam: clear them so that a later optimizer switch starts clean
+  hipLaunchKernelGGL(k_clear_flags, dim3(256), dim3(256), 0, s, h->flagU, U);
+  hipLaunchKernelGGL(k_clear_flags, dim3(256), dim3(256), 0, s, h->flagI, I);
+  BPRX_LAUNCH_CHECK(h, "k_adam_sparse");
+  return BPRX_OK;
+}
+
+int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
+  const size_t nE = (size_t)h->cfg.feat_dim * h->cfg.embed_d, nB = h->cfg.feat_dim;
+  unsigned blocks = (unsigned)((nE + nB + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
+                     h->t.v_Bp, h->dEp, nE, nB, h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg,
+                     h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->loss_acc);
+  BPRX_LAUNCH_CHECK(h, "k_dense_update");
+  return BPRX_OK;
+}
+
+int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, h->lossb, B, h->loss_acc, h->cfg.reg, loss_out);
+  BPRX_LAUNCH_CHECK(h, "k_loss_reduce");
+  return BPRX_OK;
+}
+
+int bprx_launch_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s) {
+  SparseArgs a = make_args(h, h->P);
+  dim3 grid((a.I + 63) / 64, (u1 - u0 + 3) / 4);
+  hipLaunchKernelGGL(k_score_block, grid, dim3(256), 0, s, a, u0, u1, out);
+  BPRX_LAUNCH_CHECK(h, "k_score_block");
+  return BPRX_OK;
+}

@@ -1,0 +1,196 @@
+"""Engine: one libbprx handle + the torch-ROCm tensors it is bound to.
+
+PyTorch is plumbing here (device memory, streams); every computation of the hot path runs in
+libbprx.so through the C ABI (include/bprx.h).  A missing library or a missing GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+PARAM_NAMES = ("Gu", "Gi", "Bi", "Tu", "E", "Bp")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def as_index(x, device):
+    """int64/any index array -> contiguous int32 device tensor (reference batches are int64, dataset.py:105-107)."""
+    if isinstance(x, torch.Tensor):
+        t = x.reshape(-1)
+        if t.dtype != torch.int32:
+            t = t.to(torch.int32)
+        return t.to(device, non_blocking=True).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=np.int32), device=device)
+
+
+class Engine:
+    def __init__(self, model, num_users, num_items, embed_k, embed_d=0, feat_dim=0, feat_dtype="fp32",
+                 optimizer="adam_tf23", lr=1e-3, reg=0.0, max_batch=256, device=None,
+                 beta1=0.9, beta2=0.999, epsilon=1e-7):
+        if not torch.cuda.is_available():
+            raise RuntimeError("fashionvisualexpl_recommend_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.lib = _ffi.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.model, self.optimizer = model, optimizer
+        self.U, self.I, self.k = int(num_users), int(num_items), int(embed_k)
+        self.d, self.D = (int(embed_d), int(feat_dim)) if model == "vbpr" else (0, 0)
+        self.feat_dtype = feat_dtype
+        self.max_batch = int(max_batch)
+        cfg = _ffi.Config(_ffi.ABI_VERSION, _ffi.MODEL[model], self.U, self.I, self.k, self.d, self.D,
+                          _ffi.FEAT_DTYPE[feat_dtype], _ffi.OPTIMIZER[optimizer], self.device.index, self.max_batch,
+                          lr, reg, beta1, beta2, epsilon)
+        h = C.c_void_p()
+        _ffi.check(None, self.lib.bprx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.t = {}
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bprx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state -------------------------------------------------------------------------------------------------
+    def bind(self, Gu, Gi, Bi, Tu=None, F=None, E=None, Bp=None, slots=None):
+        """Bind caller-owned device tensors (fp32, contiguous; F fp32 or bf16).  Adam slots are created here
+        (zeros, like tf.optimizers.Adam's m/v) unless given."""
+        def prep(x, shape, dtype=torch.float32):
+            if x is None:
+                return None
+            x = torch.as_tensor(x)
+            x = x.to(device=self.device, dtype=dtype).reshape(shape).contiguous()
+            return x
+        t = {"Gu": prep(Gu, (self.U, self.k)), "Gi": prep(Gi, (self.I, self.k)), "Bi": prep(Bi, (self.I,))}
+        if self.model == "vbpr":
+            fdt = torch.bfloat16 if self.feat_dtype == "bf16" else torch.float32
+            t.update(Tu=prep(Tu, (self.U, self.d)), F=prep(F, (self.I, self.D), fdt), E=prep(E, (self.D, self.d)),
+                     Bp=prep(Bp, (self.D,)))
+        if self.optimizer == "adam_tf23":
+            for n in PARAM_NAMES:
+                if t.get(n) is None:
+                    continue
+                for s in ("m_", "v_"):
+                    given = None if slots is None else slots.get(s + n)
+                    t[s + n] = torch.zeros_like(t[n]) if given is None else prep(given, tuple(t[n].shape))
+        tb = _ffi.Tables()
+        for n in _ffi.TABLE_FIELDS:
+            setattr(tb, n, None if t.get(n) is None else t[n].data_ptr())
+        _ffi.check(self.h, self.lib.bprx_bind_tables(self.h, C.byref(tb)))
+        self.t = t
+        return self
+
+    def params(self):
+        return {n: self.t[n] for n in PARAM_NAMES if self.t.get(n) is not None}
+
+    def set_hyper(self, lr, reg):
+        _ffi.check(self.h, self.lib.bprx_set_hyper(self.h, lr, reg))
+
+    @property
+    def adam_step(self):
+        return int(self.lib.bprx_get_adam_step(self.h))
+
+    @adam_step.setter
+    def adam_step(self, v):
+        _ffi.check(self.h, self.lib.bprx_set_adam_step(self.h, int(v)))
+
+    # ---- hot path ------------------------------------------------------------------------------------------------
+    def score_pairs(self, user, item):
+        u, i = as_index(user, self.device), as_index(item, self.device)
+        x = torch.empty(u.numel(), dtype=torch.float32, device=self.device)
+        for s in range(0, u.numel(), self.max_batch):            # the handle's pair scratch holds max_batch rows
+            n = min(self.max_batch, u.numel() - s)
+            _ffi.check(self.h, self.lib.bprx_score_pairs(self.h, _ptr(u[s:s + n]), _ptr(i[s:s + n]), n,
+                                                         _ptr(x[s:s + n]), _stream()))
+        return x
+
+    def step(self, user, pos, neg, want_loss=True):
+        """One train step on device int32 index tensors.  Returns the device loss scalar (no host sync)."""
+        _ffi.check(self.h, self.lib.bprx_step(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(),
+                                              _ptr(self._loss) if want_loss else None, _stream()))
+        return self._loss
+
+    def step_begin(self, user, pos, neg):
+        _ffi.check(self.h, self.lib.bprx_step_begin(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), _stream()))
+
+    def dense_grad(self):
+        """fp32 view of the handle-owned dense gradient buffer [D*d + D] (dE then dBp) for the RCCL all-reduce."""
+        p, n = C.c_void_p(), C.c_int64()
+        _ffi.check(self.h, self.lib.bprx_dense_grad(self.h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return None
+        if getattr(self, "_dense_view", None) is None:
+            self._dense_view = _DevView(p.value, n.value, self.device).tensor
+        return self._dense_view
+
+    def step_end(self, want_loss=True):
+        _ffi.check(self.h, self.lib.bprx_step_end(self.h, _ptr(self._loss) if want_loss else None, _stream()))
+        return self._loss
+
+    def score_block(self, u0, u1, out=None):
+        if out is None:
+            out = torch.empty((u1 - u0, self.I), dtype=torch.float32, device=self.device)
+        _ffi.check(self.h, self.lib.bprx_score_block(self.h, u0, u1, _ptr(out), _stream()))
+        return out
+
+    def sync_check(self):
+        _ffi.check(self.h, self.lib.bprx_sync_check(self.h, _stream()))
+
+
+class _DevView:
+    """Zero-copy torch view of library-owned device memory via __cuda_array_interface__."""
+
+    def __init__(self, ptr, n, device):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        self.tensor = torch.as_tensor(self, device=device)
+
+
+class HostSampler:
+    """bprx_sampler_*: the reference-compatible host index stream (dataset.py:83-114)."""
+
+    def __init__(self, train_lists, num_items):
+        self.lib = _ffi.lib()
+        U = len(train_lists)
+        indptr = np.zeros(U + 1, dtype=np.int64)
+        for u, l in enumerate(train_lists):
+            indptr[u + 1] = indptr[u] + len(l)
+        items = np.fromiter((i for l in train_lists for i in l), dtype=np.int32, count=int(indptr[-1]))
+        self.indptr, self.items = indptr, items
+        s = C.c_void_p()
+        rc = self.lib.bprx_sampler_create(indptr.ctypes.data, items.ctypes.data, U, num_items, C.byref(s))
+        if rc < 0:
+            raise _ffi.BprxError(rc, "bprx_sampler_create: invalid training lists (item id out of range?)")
+        self.s = s
+
+    def count(self, batch_size, epochs):
+        return int(self.lib.bprx_sampler_count(self.s, batch_size, epochs))
+
+    def ref_stream(self, batch_size, epochs, py_seed=0, np_seed=0):
+        n = self.count(batch_size, epochs)
+        u, i, j = (np.empty(n, np.int32) for _ in range(3))
+        got = self.lib.bprx_sampler_ref_stream(self.s, batch_size, epochs, py_seed, np_seed,
+                                               u.ctypes.data, i.ctypes.data, j.ctypes.data, n)
+        if got < 0:
+            raise _ffi.BprxError(int(got), "bprx_sampler_ref_stream failed (a user whose positives cover every item?)")
+        return u[:got], i[:got], j[:got]
+
+    def __del__(self):
+        try:
+            if getattr(self, "s", None):
+                self.lib.bprx_sampler_destroy(self.s)
+                self.s = None
+        except Exception:
+            pass

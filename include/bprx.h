@@ -1,0 +1,137 @@
+/*
+ * bprx.h -- C ABI of libbprx.so: the MI355X (gfx950) BPRMF / VBPR training hot path.
+ *
+ * The reference (peternara/FashionVisualExpl-recommend) has NO native plugin/FFI interface for this
+ * path: it is TensorFlow-2.3 eager Python.  Its boundary is the Python class surface
+ *     src/recommender/models/BPRMF.py:55  call            :78  predict_all   :87  train_step
+ *     src/recommender/models/VBPR.py:59   call            :88  predict_all   :99  train_step
+ *     src/dataset/dataset.py:83           all_triple_batches (index stream)
+ *     src/recommender/Evaluator.py:82     _eval_by_user     (HR/nDCG/AUC/P/R definition)
+ * Each entry point below names the reference lines it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.  Plain pointers and sizes only: no torch / TF types.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, a negative BPRX_E_* code otherwise; bprx_last_error() gives text.
+ *     No exception crosses the ABI.  Index range errors are detected on the device and reported by the next
+ *     bprx_sync_check() (indices are clamped so that no kernel ever faults).
+ *   - All table / index / output pointers are DEVICE pointers owned by the caller (e.g. torch tensors); the
+ *     handle owns only its scratch.  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     all work is enqueued, nothing synchronises unless stated.
+ *   - A handle is bound to one device and is not re-entrant.  One process per GPU.
+ *   - Tables are row-major fp32 exactly like the reference's tf.Variables (BPRMF.py:48-50, VBPR.py:44-54).
+ *     F may be fp32 [I,D] or bf16 [I,D] (raw uint16 bit patterns).
+ */
+#ifndef BPRX_H_
+#define BPRX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPRX_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define BPRX_API __attribute__((visibility("default")))
+#else
+#define BPRX_API
+#endif
+
+enum { BPRX_MODEL_BPRMF = 0, BPRX_MODEL_VBPR = 1 };
+enum { BPRX_OPT_SGD = 0, BPRX_OPT_ADAM_TF23 = 1 };
+enum { BPRX_F_FP32 = 0, BPRX_F_BF16 = 1 };
+
+enum {
+  BPRX_OK = 0,
+  BPRX_E_INVALID = -1,   /* bad argument / unsupported configuration */
+  BPRX_E_STATE = -2,     /* call order (tables not bound, ...) */
+  BPRX_E_HIP = -3,       /* HIP runtime error */
+  BPRX_E_RANGE = -4,     /* an index was out of range (seen by bprx_sync_check) */
+  BPRX_E_NOMEM = -5
+};
+
+typedef struct bprx_handle bprx_handle;
+typedef struct bprx_sampler bprx_sampler;
+
+typedef struct {
+  int32_t abi_version;   /* BPRX_ABI_VERSION */
+  int32_t model;         /* BPRX_MODEL_*            train_rec.py:75-78 (--rec bprmf|vbpr) */
+  int32_t num_users;     /* rows of Gu/Tu held by THIS handle (a shard when user-sharded) */
+  int32_t num_items;     /* rows of Gi/Bi/F held by THIS handle (a shard when item-sharded) */
+  int32_t embed_k;       /* --embed_k  train_rec.py:42 */
+  int32_t embed_d;       /* --embed_d  train_rec.py:43 (VBPR only, else 0) */
+  int32_t feat_dim;      /* D = F.shape[1]  visual_loader_mixin.py:31 (VBPR only, else 0) */
+  int32_t feat_dtype;    /* BPRX_F_* */
+  int32_t optimizer;     /* BPRX_OPT_* ; reference = Adam (BPRMF.py:52, VBPR.py:56) */
+  int32_t device;        /* HIP device ordinal */
+  int64_t max_batch;     /* largest B any bprx_step/bprx_score_pairs call will use */
+  float lr;              /* --lr   train_rec.py:28 */
+  float reg;             /* --reg  train_rec.py:44,69 */
+  float beta1, beta2, epsilon; /* adam_tf23: 0.9, 0.999, 1e-7 (tf.optimizers.Adam defaults) */
+} bprx_config;
+
+/* Device pointers to the model state.  Unused entries (BPRMF: Tu,F,E,Bp; sgd: every m_/v_) are NULL. */
+typedef struct {
+  float *Gu;       /* [U,k]  BPRMF.py:49 */
+  float *Gi;       /* [I,k]  BPRMF.py:50 */
+  float *Bi;       /* [I]    BPRMF.py:48 */
+  float *Tu;       /* [U,d]  VBPR.py:46  */
+  const void *F;   /* [I,D]  VBPR.py:49, frozen; fp32 or bf16 per feat_dtype */
+  float *E;        /* [D,d]  VBPR.py:52  */
+  float *Bp;       /* [D]    VBPR.py:44 ([D,1]) */
+  float *m_Gu, *v_Gu, *m_Gi, *v_Gi, *m_Bi, *v_Bi, *m_Tu, *v_Tu, *m_E, *v_E, *m_Bp, *v_Bp; /* Adam slots */
+} bprx_tables;
+
+BPRX_API int bprx_abi_version(void);
+
+/* Model(data, params) constructor scratch (BPRMF.py:23-53, VBPR.py:19-57). */
+BPRX_API int bprx_create(const bprx_config *cfg, bprx_handle **out);
+BPRX_API int bprx_destroy(bprx_handle *h);
+BPRX_API const char *bprx_last_error(const bprx_handle *h); /* h == NULL: error of the last failed bprx_create */
+
+BPRX_API int bprx_bind_tables(bprx_handle *h, const bprx_tables *t);
+BPRX_API int bprx_set_hyper(bprx_handle *h, float lr, float reg);           /* train_rec.py:69 (args.reg = reg) */
+BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations);         /* optimizer.iterations (resume) */
+BPRX_API int64_t bprx_get_adam_step(const bprx_handle *h);
+
+/* Model.call((user,item)) -> xui        BPRMF.py:55-76 / VBPR.py:59-86.   x: fp32 [B] */
+BPRX_API int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32_t *item, int64_t B, float *x, void *stream);
+
+/* Model.train_step((user,pos,neg)) -> loss   BPRMF.py:87-125 / VBPR.py:99-144.
+   Batch-synchronous: all gradients from pre-update values, duplicate rows summed, one optimizer update.
+   loss_out: device fp32 scalar (data term + regularisation, as the reference's loss.numpy()); may be NULL. */
+BPRX_API int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
+              float *loss_out, void *stream);
+
+/* The same step in two halves, for item-sharded multi-GPU VBPR: after _begin the dense gradient of the
+   shared parameters ([D,d] dE followed by [D] dBp, fp32, WITHOUT the 2*reg*E term) sits in the buffer
+   returned by bprx_dense_grad(); the caller all-reduces it (RCCL) and calls _end, which adds the
+   regularisation term and applies the optimizer to E/Bp.  bprx_step == _begin + _end. */
+BPRX_API int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
+                    void *stream);
+BPRX_API int bprx_dense_grad(bprx_handle *h, float **ptr, int64_t *count);
+BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
+
+/* Model.predict_all() rows [u0,u1)   BPRMF.py:78-85 / VBPR.py:88-97.   out: fp32 [(u1-u0), I] */
+BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream);
+
+/* Synchronise `stream` and report deferred device-side errors (index out of range). */
+BPRX_API int bprx_sync_check(bprx_handle *h, void *stream);
+
+/* ---- index stream (HOST side) --------------------------------------------------------------------------
+   DataLoader.all_triple_batches  dataset.py:83-114: per epoch random.shuffle(users) (Python MT19937), walk
+   every positive of each user, negative by rejection on np.random.randint (NumPy-legacy MT19937).
+   CSR of training_list on the HOST.  bprx_sampler_count = floor(N/bs)*bs*epochs (all epochs when that is 0).
+   Output arrays are HOST int32 (the stream is inherently sequential; 12 B/triplet). */
+BPRX_API int bprx_sampler_create(const int64_t *indptr, const int32_t *items, int32_t num_users, int32_t num_items,
+                        bprx_sampler **out);
+BPRX_API int bprx_sampler_destroy(bprx_sampler *s);
+BPRX_API int64_t bprx_sampler_count(const bprx_sampler *s, int32_t batch_size, int32_t epochs);
+BPRX_API int64_t bprx_sampler_ref_stream(bprx_sampler *s, int32_t batch_size, int32_t epochs, uint32_t py_seed,
+                                uint32_t np_seed, int32_t *user, int32_t *pos, int32_t *neg, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPRX_H_ */

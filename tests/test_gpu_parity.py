@@ -1,0 +1,153 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+fp32 tolerance: 1e-5 relative on scores (north_star); bf16 feature path: stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from fashionvisualexpl_recommend_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(**kw):
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    return Engine(**kw)
+
+
+def _tables(U, I, k, d=0, D=0, seed=0, bf16=False):
+    rs = np.random.RandomState(seed)
+    t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k),
+             Bi=(rs.standard_normal(I) * 0.01).astype(np.float32))
+    if d:
+        F = synth.make_features(I, D, seed=seed)
+        F = (F / np.abs(F).max()).astype(np.float32)
+        if bf16:
+            F = orc.bf16_round(F)
+        t.update(Tu=synth.glorot_uniform(rs, U, d), F=F, E=synth.glorot_uniform(rs, D, d),
+                 Bp=synth.glorot_uniform(rs, D, 1).reshape(-1))
+    return t
+
+
+def _batch(U, I, B, seed, dup_user=None):
+    rs = np.random.RandomState(seed)
+    u, i, j = rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B)
+    if dup_user is not None:
+        u[:max(1, B // 4)] = dup_user
+    return u.astype(np.int32), i.astype(np.int32), j.astype(np.int32)
+
+
+def _dev(a):
+    return torch.as_tensor(a, device="cuda")
+
+
+def _close(got, want, rtol, atol, msg=""):
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=msg)
+
+
+@pytest.mark.parametrize("k", [1, 5, 32, 128, 200, 256])
+def test_bprmf_score_pairs(k):
+    U, I, B = 300, 500, 1000
+    t = _tables(U, I, k, seed=k)
+    e = _engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="sgd", max_batch=B).bind(**t)
+    u, i, _ = _batch(U, I, B, 1)
+    got = e.score_pairs(u, i).cpu().numpy()
+    e.sync_check()
+    want = orc.OracleModel(**t).score_pairs(u, i)
+    _close(got, want, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("k,opt,reg", [(32, "sgd", 0.0), (32, "sgd", 1e-2), (32, "adam_tf23", 0.0),
+                                       (32, "adam_tf23", 1e-3), (128, "sgd", 1e-3), (5, "sgd", 1e-3),
+                                       (200, "adam_tf23", 1e-3)])
+def test_bprmf_steps_match_oracle(k, opt, reg):
+    U, I, B = 64, 96, 256                       # B > U, I: heavy duplicate rows in every batch
+    t = _tables(U, I, k, seed=2)
+    lr = 0.05 if opt == "sgd" else 0.01
+    e = _engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer=opt, lr=lr, reg=reg, max_batch=B).bind(**t)
+    o = orc.OracleModel(**t)
+    for step in range(4):
+        u, i, j = _batch(U, I, B, 10 + step, dup_user=7)
+        if step == 1:
+            j[:8] = i[:8]                        # degenerate i == j triplets
+        loss = e.step(_dev(u), _dev(i), _dev(j)).item()
+        want = o.step(u, i, j, opt, lr, reg)
+        assert loss == pytest.approx(want, rel=2e-5)
+        for n in ("Gu", "Gi", "Bi"):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), 2e-5, 2e-6, "%s step %d" % (n, step))
+    e.sync_check()
+
+
+def test_bprmf_single_triplet_and_clip():
+    """B = 1 (the reference's tf.squeeze breaks there, BPRMF.py:70-72) and the clip_by_value dead zone."""
+    t = _tables(4, 4, 8, seed=3)
+    t["Bi"][:] = 0
+    t["Bi"][1] = 100.0
+    e = _engine(model="bprmf", num_users=4, num_items=4, embed_k=8, optimizer="sgd", lr=0.1, max_batch=4).bind(**t)
+    loss = e.step(_dev(np.array([0], np.int32)), _dev(np.array([0], np.int32)), _dev(np.array([1], np.int32))).item()
+    assert loss == pytest.approx(80.0, rel=1e-6)
+    np.testing.assert_array_equal(e.t["Gu"].cpu().numpy(), t["Gu"])       # g == 0 below -80: nothing moves
+    np.testing.assert_array_equal(e.t["Gi"].cpu().numpy(), t["Gi"])
+
+
+def test_out_of_range_index_is_reported_not_faulted():
+    from fashionvisualexpl_recommend_amd import _ffi
+    t = _tables(8, 8, 8, seed=4)
+    e = _engine(model="bprmf", num_users=8, num_items=8, embed_k=8, optimizer="sgd", max_batch=8).bind(**t)
+    e.score_pairs(np.array([0, 9], np.int32), np.array([0, 1], np.int32))
+    with pytest.raises(_ffi.BprxError) as ei:
+        e.sync_check()
+    assert ei.value.code == _ffi.E_RANGE
+    e.sync_check()                                                          # flag cleared
+
+
+def test_bprmf_predict_all():
+    U, I, k = 70, 130, 32
+    t = _tables(U, I, k, seed=5)
+    e = _engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="sgd", max_batch=8).bind(**t)
+    got = torch.cat([e.score_block(0, 33), e.score_block(33, U)]).cpu().numpy()
+    _close(got, orc.OracleModel(**t).predict_all(), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("k,d,D,dtype", [(32, 20, 128, "fp32"), (8, 5, 100, "fp32"), (64, 64, 4096, "fp32"),
+                                         (32, 20, 128, "bf16"), (64, 64, 4096, "bf16"), (16, 128, 256, "bf16"),
+                                         (16, 256, 128, "bf16")])
+def test_vbpr_score_pairs_and_predict(k, d, D, dtype):
+    U, I, B = 40, 150, 333
+    bf = dtype == "bf16"
+    t = _tables(U, I, k, d, D, seed=6, bf16=bf)
+    e = _engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype=dtype,
+                optimizer="sgd", max_batch=B).bind(**t)
+    u, i, _ = _batch(U, I, B, 2)
+    got = e.score_pairs(u, i).cpu().numpy()
+    o = orc.OracleModel(**t, quant=1 if bf else 0)
+    want = o.score_pairs(u, i)
+    # fp32: north_star 1e-5 relative.  bf16: same operands as the oracle's quant=1 mode, fp32 MFMA accumulation.
+    _close(got, want, 1e-5, 2e-6 if not bf else 2e-5)
+    _close(e.score_block(0, U).cpu().numpy(), o.predict_all(), 1e-5, 2e-6 if not bf else 2e-5)
+    e.sync_check()
+
+
+@pytest.mark.parametrize("k,d,D,dtype,opt,reg", [(32, 20, 128, "fp32", "sgd", 1e-3), (32, 20, 128, "fp32", "adam_tf23", 1e-3),
+                                                 (8, 5, 100, "fp32", "sgd", 0.0),
+                                                 (32, 20, 128, "bf16", "sgd", 1e-3), (64, 64, 512, "bf16", "adam_tf23", 1e-3),
+                                                 (16, 128, 256, "bf16", "sgd", 0.0)])
+def test_vbpr_steps_match_oracle(k, d, D, dtype, opt, reg):
+    U, I, B = 48, 200, 256
+    bf = dtype == "bf16"
+    t = _tables(U, I, k, d, D, seed=7, bf16=bf)
+    lr = 0.05 if opt == "sgd" else 0.01
+    e = _engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype=dtype,
+                optimizer=opt, lr=lr, reg=reg, max_batch=B).bind(**t)
+    o = orc.OracleModel(**t, quant=1 if bf else 0)
+    # bf16: W and E are rounded to bf16 on both sides, but W's fp32 value differs in the last bits (atomic
+    # order), so a rounding boundary can flip: tolerance 2e-3 of the gradient scale on E/Bp, tight elsewhere.
+    rt, at = (2e-5, 2e-6) if not bf else (2e-3, 2e-5)
+    for step in range(3):
+        u, i, j = _batch(U, I, B, 20 + step, dup_user=5)
+        loss = e.step(_dev(u), _dev(i), _dev(j)).item()
+        want = o.step(u, i, j, opt, lr, reg)
+        assert loss == pytest.approx(want, rel=1e-4 if bf else 2e-5)
+        for n in ("Gu", "Gi", "Bi", "Tu", "E", "Bp"):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step))
+    e.sync_check()
