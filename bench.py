@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR triplets/s of the VBPR train step on MI355X (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL.)
+
+A "step" is one batch-synchronous VBPR train step (bprx_step: projection of every item row, per-triplet
+forward/backward, dense E|Bp gradient, sparse + dense SGD) over one batch of B synthetic triplets whose index
+tensors, factor tables and bf16 feature table are resident in HBM before the timed region starts.
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, HIP events on the launch stream),
+`kernels` (per-kernel average ms), `step_roofline` (SURVEY 8(d) per-triplet accounting), `cpu_baseline`
+(the CPU oracle timed on a bounded, ratio-preserving sample; rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: VBPR k=64, 4096-d CNN feats, 100K users x 50K items, bf16, 1 x MI355X
+    "c2": dict(model="vbpr", U=100_000, I=50_000, k=64, d=64, D=4096, dtype="bf16", B=65_536),
+    # BASELINE.json configs[2] per-GPU shard shape (BPRMF k=128, 5M x 1M over 8 GPUs -> 625K users/GPU)
+    "c3shard": dict(model="bprmf", U=625_000, I=1_000_000, k=128, d=0, D=0, dtype="fp32", B=65_536),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam_tf23"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=20)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_triplet(w, B):
+    """fused single pass, every touched row read once and (if trainable) written once, int32 indices."""
+    k, d, D = w["k"], w["d"], w["D"]
+    s = {"fp32": 4, "bf16": 2}[w["dtype"]]
+    b = 24 * k + 28
+    if w["model"] == "vbpr":
+        b += 8 * d + 2 * D * s + 2.0 * (D * (d + 1)) * 4 / B
+    return b
+
+
+def make_state(w, device, seed, torch):
+    """Synthetic tables generated directly in HBM (no dataset/checkpoint exists offline): Glorot-uniform factors,
+    |N(0,1)| half-sparse features divided by their global max (visual_loader_mixin.py:30) and stored as bf16."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def glorot(r, c):
+        lim = (6.0 / (r + c)) ** 0.5
+        return (torch.rand((r, c), generator=g, device=device, dtype=torch.float32) * 2 - 1) * lim
+    t = dict(Gu=glorot(w["U"], w["k"]), Gi=glorot(w["I"], w["k"]), Bi=torch.zeros(w["I"], device=device))
+    if w["model"] == "vbpr":
+        I, D, d = w["I"], w["D"], w["d"]
+        F = torch.empty((I, D), device=device, dtype=torch.bfloat16 if w["dtype"] == "bf16" else torch.float32)
+        mx = 0.0
+        chunk = 8192
+        for s in range(0, I, chunk):                      # chunked: never more than ~400 MB of fp32 temporaries
+            n = min(chunk, I - s)
+            f = torch.randn((n, D), generator=g, device=device).abs_()
+            f *= (torch.rand((n, D), generator=g, device=device) < 0.5)
+            mx = max(mx, float(f.max()))
+            F[s:s + n] = f.to(F.dtype)
+        F.div_(mx)
+        t.update(Tu=glorot(w["U"], d), F=F, E=glorot(D, d), Bp=glorot(D, 1).reshape(-1))
+    return t
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from fashionvisualexpl_recommend_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)      # "nccl" IS RCCL on ROCm
+
+    w = dict(WORKLOADS[args.workload])
+    if args.batch:
+        w["B"] = args.batch
+    B, K, W = w["B"], args.steps, args.warmup
+
+    # Weak scaling: every rank holds one shard of this shape (item + user shard, item-sharded VBPR); the dense
+    # shared parameters E|Bp are kept identical on all ranks by an RCCL all-reduce of their gradient every step.
+    # Round 1: each rank's synthetic triplets reference its own user shard (no user-row exchange yet).
+    tables = make_state(w, device, 1234 + rank, torch)
+    if world > 1 and w["model"] == "vbpr":
+        for n in ("E", "Bp"):
+            dist.broadcast(tables[n], src=0)
+    eng = Engine(model=w["model"], num_users=w["U"], num_items=w["I"], embed_k=w["k"], embed_d=w["d"], feat_dim=w["D"],
+                 feat_dtype=w["dtype"], optimizer=args.optimizer, lr=0.05, reg=1e-4, max_batch=B,
+                 device=local_rank).bind(**tables)
+
+    gi = torch.Generator(device=device)
+    gi.manual_seed(99 + rank)
+    nb = min(K + W, 16)                                   # distinct resident index batches, cycled
+    batches = [(torch.randint(w["U"], (B,), generator=gi, device=device, dtype=torch.int32),
+                torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32),
+                torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32)) for _ in range(nb)]
+    dense = eng.dense_grad() if (world > 1 and w["model"] == "vbpr") else None
+
+    def one_step(s):
+        u, i, j = batches[s % nb]
+        if dense is None:
+            eng.step(u, i, j, want_loss=False)
+        else:
+            eng.step_begin(u, i, j)
+            dist.all_reduce(dense)                        # RCCL over xGMI, same stream
+            eng.step_end(want_loss=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(W):
+        one_step(s)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(K):
+        one_step(W + s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    eng.sync_check()
+
+    # per-kernel durations: a second pass over the same K steps with HIP events around every kernel launch
+    eng.profile(True)
+    for s in range(K):
+        one_step(W + s)
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
+    loss = float(eng.step(*batches[0]).item())           # sanity: the path produced a finite loss
+    assert np.isfinite(loss), loss
+
+    if rank == 0:
+        value = world * B * K / elapsed
+        per_trip = algorithmic_bytes_per_triplet(w, B)
+        kernels = {p: {"avg_ms": ms / n, "launches": n} for p, (ms, n) in prof.items()}
+        dom = max(kernels, key=lambda p: kernels[p]["avg_ms"])
+        s = {"fp32": 4, "bf16": 2}[w["dtype"]]
+        if w["model"] == "vbpr":
+            PS = 16 * ((w["d"] + 1 + 15) // 16)
+            kern_bytes = {   # algorithmic bytes per launch, per kernel (DESIGN.md "Kernels")
+                "proj_fwd": w["I"] * (w["D"] * s + PS * 4) + PS * w["D"] * 2,
+                "proj_bwd": w["I"] * (w["D"] * s + PS * 4) + w["D"] * PS * 4,
+                "triplet_grad": B * (24 * w["k"] + 28 + 8 * w["d"] + 2 * PS * 4 + 2 * PS * 4) / 1.0,
+                "apply": 3 * B * 0 + B * (12 * (w["k"] + w["d"]) + 24 * w["k"]),
+            }
+        else:
+            kern_bytes = {"triplet_grad": B * (24 * w["k"] + 28), "apply": B * 36 * w["k"]}
+        rl = None
+        if dom in kern_bytes:
+            ach = kern_bytes[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+            rl = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": kern_bytes[dom],
+                  "avg_ms": kernels[dom]["avg_ms"]}
+        out = {
+            "metric": "BPR triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": w["dtype"] if w["model"] == "vbpr" else "fp32", "data": "synthetic",
+            "config": {"workload": "%s: %s k=%d d=%d D=%d, %d users x %d items per GPU, %s features, B=%d per GPU, %s"
+                                   % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
+                                      w["dtype"], B, args.optimizer),
+                       "global_batch": B * world, "parallelism": "item-shard x%d, all-reduce(E|Bp)" % world if world > 1 else "single",
+                       "sampler": "pre-generated uniform (u,i,j), resident"},
+            "roofline": rl, "kernels": kernels,
+            "step_roofline": {"bytes_per_triplet": per_trip, "achieved": value * per_trip / 1e9 / world,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value * per_trip / 1e9 / world / HBM_PEAK_GBS},
+            "loss_after": loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, tables, args.cpu_sample_steps, args.optimizer)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, tables, steps, optimizer):
+    """The CPU oracle (oracle/bpr_oracle.c, OpenMP) on a bounded sample that preserves the workload's B:U:I ratios:
+    a 1/8 slice of the users and items with B/8 triplets per step (same rows-per-triplet duplication as the
+    full batch), same k/d/D and the same bf16 operand rounding."""
+    from oracle import oracle as orc
+    f = 8
+    U, I, B = max(w["U"] // f, 8), max(w["I"] // f, 8), max(w["B"] // f, 8)
+    cpu = lambda t, n: t[:n].float().cpu().numpy()
+    kw = dict(Gu=cpu(tables["Gu"], U), Gi=cpu(tables["Gi"], I), Bi=cpu(tables["Bi"], I))
+    if w["model"] == "vbpr":
+        kw.update(Tu=cpu(tables["Tu"], U), F=cpu(tables["F"], I), E=tables["E"].cpu().numpy(),
+                  Bp=tables["Bp"].cpu().numpy(), quant=1 if w["dtype"] == "bf16" else 0)
+    o = orc.OracleModel(**kw)
+    rs = np.random.RandomState(5)
+    cores = orc.lib().orc_num_threads()
+    o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 0.05, 1e-4)   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 0.05, 1e-4)
+    dt = time.perf_counter() - t0
+    return {"value": steps * B / dt, "unit": "triplets/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of B=%d triplets on a 1/%d slice (%d users x %d items) of the same tables, same k/d/D"
+                      % (steps, B, f, U, I)}
+
+
+if __name__ == "__main__":
+    main()

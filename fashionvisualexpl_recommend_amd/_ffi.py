@@ -15,6 +15,7 @@ MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
 FEAT_DTYPE = {"fp32": 0, "bf16": 1}
 E_RANGE = -4
+PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce"]
 
 
 class BprxError(RuntimeError):
@@ -68,6 +69,8 @@ def lib():
         "bprx_step_end": (C.c_int, [vp, vp, vp]),
         "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
         "bprx_sync_check": (C.c_int, [vp, vp]),
+        "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
+        "bprx_profile_read": (C.c_int, [vp, vp, vp]),
         "bprx_sampler_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "bprx_sampler_destroy": (C.c_int, [vp]),
         "bprx_sampler_count": (i64, [vp, i32, i32]),
@@ -84,7 +87,8 @@ def lib():
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
-           "bprx_dense_grad", "bprx_step_end", "bprx_score_block", "bprx_sync_check", "bprx_sampler_create",
+           "bprx_dense_grad", "bprx_step_end", "bprx_score_block", "bprx_sync_check", "bprx_profile_enable",
+           "bprx_profile_read", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]
 
 

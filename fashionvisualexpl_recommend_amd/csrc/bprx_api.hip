@@ -92,6 +92,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     delete h;
     return BPRX_E_NOMEM;
   }
+  h->prof_pending = new std::vector<bprx_handle::ProfRec>();
+  h->prof_free = new std::vector<hipEvent_t>();
   *out = h;
   return BPRX_OK;
 #undef CFAIL
@@ -101,7 +103,30 @@ extern "C" int bprx_destroy(bprx_handle *h) {
   if (!h) return BPRX_OK;
   (void)hipSetDevice(h->cfg.device);
   free_scratch(h);
+  if (h->prof_pending) { for (auto &r : *h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } delete h->prof_pending; }
+  if (h->prof_free) { for (auto e : *h->prof_free) (void)hipEventDestroy(e); delete h->prof_free; }
   delete h;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_profile_enable(bprx_handle *h, int on) {
+  if (!h) return BPRX_E_INVALID;
+  h->prof = on != 0;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches) {
+  if (!h || !ms || !launches) return BPRX_E_INVALID;
+  for (auto &r : *h->prof_pending) {
+    BPRX_HIP(h, hipEventSynchronize(r.b));
+    float t = 0.f;
+    BPRX_HIP(h, hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.phase] += (double)t;
+    launches[r.phase] += 1;
+    h->prof_free->push_back(r.a);
+    h->prof_free->push_back(r.b);
+  }
+  h->prof_pending->clear();
   return BPRX_OK;
 }
 

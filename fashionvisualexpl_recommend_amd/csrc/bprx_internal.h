@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "bprx.h"
 
 struct bprx_handle {
@@ -30,6 +32,28 @@ struct bprx_handle {
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
+  // per-kernel HIP-event timing (bprx_profile_*)
+  bool prof;
+  struct ProfRec { int phase; hipEvent_t a, b; };
+  std::vector<ProfRec> *prof_pending;
+  std::vector<hipEvent_t> *prof_free;
+};
+
+// RAII: records an event pair around one kernel launch when profiling is on.
+struct BprxProfScope {
+  bprx_handle *h; hipStream_t s; hipEvent_t a, b; int phase; bool on;
+  BprxProfScope(bprx_handle *h_, int phase_, hipStream_t s_) : h(h_), s(s_), phase(phase_), on(h_->prof) {
+    if (!on) return;
+    auto get = [&]() { hipEvent_t e; if (!h->prof_free->empty()) { e = h->prof_free->back(); h->prof_free->pop_back(); }
+                       else (void)hipEventCreate(&e); return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, s);
+  }
+  ~BprxProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    h->prof_pending->push_back({phase, a, b});
+  }
 };
 
 #define BPRX_FAIL(h, code, ...)                                   \

@@ -276,6 +276,7 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
   if (h->cfg.feat_dtype != BPRX_F_BF16) return BPRX_OK;
   const int D = h->cfg.feat_dim;
+  BprxProfScope ps(h, BPRX_PHASE_CAST_ET, s);
   dim3 grid((D + 255) / 256, h->PS);
   hipLaunchKernelGGL(k_cast_Et, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint16_t *)h->Et, D, h->cfg.embed_d, h->PS);
   BPRX_LAUNCH_CHECK(h, "k_cast_Et");
@@ -284,6 +285,7 @@ int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
 
 int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   if (nrows <= 0) return BPRX_OK;
+  BprxProfScope ps(h, BPRX_PHASE_PROJ_FWD, s);
   if (h->cfg.feat_dtype == BPRX_F_BF16) {
     const int NT = h->PS / 16;
 #define CALL(N) launch_fwd_nt<N>(h, rows, nrows, Pout, s)
@@ -303,14 +305,19 @@ int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, d = h->cfg.embed_d, I = h->cfg.num_items;
   if (h->cfg.feat_dtype == BPRX_F_BF16) {
     const int NT = h->PS / 16;
+    {
+      BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
 #define CALL(N) launch_bwd_nt<N>(h, s)
-    NT_SWITCH(NT, CALL)
+      NT_SWITCH(NT, CALL)
 #undef CALL
+    }
     BPRX_LAUNCH_CHECK(h, "k_proj_bwd_bf16");
     const size_t n = (size_t)D * h->PS;
+    BprxProfScope ps(h, BPRX_PHASE_REDUCE, s);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK, D, d, h->PS, h->dEp);
     BPRX_LAUNCH_CHECK(h, "k_reduce_parts");
   } else {
+    BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
     hipLaunchKernelGGL(k_proj_bwd_f32, dim3(D), dim3(256), 0, s, (const float *)h->t.F, I, D, h->W, d, h->PS, h->dEp);
     BPRX_LAUNCH_CHECK(h, "k_proj_bwd_f32");
   }

@@ -402,6 +402,7 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   SparseArgs a = make_args(h, h->P);
   const bool vec = vec_ok(h);
   const int G = pick_group(a.k, a.d, vec);
+  BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
   if (a.d) BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
@@ -411,6 +412,7 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
 int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t, hipStream_t s) {
   SparseArgs a = make_args(h, nullptr);
   const size_t U = a.U, I = a.I, k = a.k, d = a.d;
+  BprxProfScope ps(h, BPRX_PHASE_APPLY, s);
   if (h->cfg.optimizer == BPRX_OPT_SGD) {
     const bool vec = vec_ok(h);
     const int G = pick_group(a.k, a.d, vec);
@@ -439,6 +441,7 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   const size_t nE = (size_t)h->cfg.feat_dim * h->cfg.embed_d, nB = h->cfg.feat_dim;
   unsigned blocks = (unsigned)((nE + nB + 255) / 256);
   if (blocks > 1024) blocks = 1024;
+  BprxProfScope ps(h, BPRX_PHASE_DENSE, s);
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
                      h->t.v_Bp, h->dEp, nE, nB, h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg,
                      h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->loss_acc);
@@ -447,6 +450,7 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
 }
 
 int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStream_t s) {
+  BprxProfScope ps(h, BPRX_PHASE_LOSS, s);
   hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, h->lossb, B, h->loss_acc, h->cfg.reg, loss_out);
   BPRX_LAUNCH_CHECK(h, "k_loss_reduce");
   return BPRX_OK;

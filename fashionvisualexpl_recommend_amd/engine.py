@@ -146,6 +146,16 @@ class Engine:
         _ffi.check(self.h, self.lib.bprx_score_block(self.h, u0, u1, _ptr(out), _stream()))
         return out
 
+    def profile(self, on):
+        _ffi.check(self.h, self.lib.bprx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """{phase: (total_ms, launches)} accumulated since the last read (HIP events on the launch stream)."""
+        ms = np.zeros(len(_ffi.PHASES), np.float64)
+        n = np.zeros(len(_ffi.PHASES), np.int64)
+        _ffi.check(self.h, self.lib.bprx_profile_read(self.h, ms.ctypes.data, n.ctypes.data))
+        return {p: (float(ms[i]), int(n[i])) for i, p in enumerate(_ffi.PHASES) if n[i]}
+
     def sync_check(self):
         _ffi.check(self.h, self.lib.bprx_sync_check(self.h, _stream()))
 

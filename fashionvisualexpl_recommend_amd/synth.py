@@ -54,3 +54,27 @@ def glorot_uniform(rs, rows, cols):
     stream is not reproducible without TF, so parity tests inject identical tables on both sides."""
     lim = np.sqrt(6.0 / (rows + cols))
     return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
+
+
+def make_interactions_clustered(num_users, num_items, per_user=22, clusters=20, p_in=0.9, seed=2024):
+    """Like make_interactions, but learnable: users and items fall into `clusters` groups and a user draws each of
+    its items from its own group with probability p_in (else uniformly).  Used where a test needs HR@K well above
+    the random-ranking level so that a metric comparison is informative."""
+    rs = np.random.RandomState(seed)
+    item_cluster = rs.randint(clusters, size=num_items)
+    by_cluster = [np.flatnonzero(item_cluster == c) for c in range(clusters)]
+    train, val, test = [], [], []
+    for _ in range(num_users):
+        c = rs.randint(clusters)
+        chosen = []
+        seen = set()
+        while len(chosen) < per_user:
+            pool = by_cluster[c] if (rs.random_sample() < p_in and len(by_cluster[c]) > per_user) else None
+            it = int(pool[rs.randint(len(pool))]) if pool is not None else int(rs.randint(num_items))
+            if it not in seen:
+                seen.add(it)
+                chosen.append(it)
+        train.append(sorted(chosen[:per_user - 2]))
+        val.append([chosen[per_user - 2]])
+        test.append([chosen[per_user - 1]])
+    return train, val, test

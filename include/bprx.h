@@ -116,6 +116,17 @@ BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
 /* Model.predict_all() rows [u0,u1)   BPRMF.py:78-85 / VBPR.py:88-97.   out: fp32 [(u1-u0), I] */
 BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream);
 
+/* Per-kernel timing with HIP events recorded on the caller's stream around every kernel of bprx_step
+   (used by bench.py for the roofline figure; off by default, costs two event records per kernel when on).
+   bprx_profile_read synchronises the pending events, ADDS the elapsed milliseconds and launch counts of each
+   phase into ms[BPRX_PHASE_COUNT] / launches[BPRX_PHASE_COUNT] and clears the pending list. */
+enum {
+  BPRX_PHASE_CAST_ET = 0, BPRX_PHASE_PROJ_FWD = 1, BPRX_PHASE_TRIPLET = 2, BPRX_PHASE_PROJ_BWD = 3,
+  BPRX_PHASE_REDUCE = 4, BPRX_PHASE_APPLY = 5, BPRX_PHASE_DENSE = 6, BPRX_PHASE_LOSS = 7, BPRX_PHASE_COUNT = 8
+};
+BPRX_API int bprx_profile_enable(bprx_handle *h, int on);
+BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);
+
 /* Synchronise `stream` and report deferred device-side errors (index out of range). */
 BPRX_API int bprx_sync_check(bprx_handle *h, void *stream);
 

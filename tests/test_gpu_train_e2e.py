@@ -1,4 +1,4 @@
-"""Config 1 end to end (BPRMF k=32, 1K x 2K, bs 256, 5 epochs, reference optimiser semantics):
+"""Config 1 shape end to end (BPRMF k=32, 1K x 2K clustered interactions, bs 256, 5 epochs; both optimisers):
 GPU engine vs CPU oracle on the IDENTICAL reference index stream -> HR@10 / NDCG@10 within 1e-3 (north_star)."""
 from argparse import Namespace
 
@@ -11,11 +11,11 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("opt,lr", [("adam_tf23", 1e-3), ("sgd", 0.05)])
+@pytest.mark.parametrize("opt,lr", [("adam_tf23", 5e-3), ("sgd", 0.5)])
 def test_c1_bprmf_metric_parity(tmp_path, opt, lr, capsys):
     from fashionvisualexpl_recommend_amd.dataset import DataLoader
     from fashionvisualexpl_recommend_amd.models import BPRMF
-    tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
+    tr, va, te = synth.make_interactions_clustered(1000, 2000, per_user=22, clusters=20, p_in=0.9, seed=2024)
     synth.write_dataset(str(tmp_path), "c1", tr, va, te, 2000)
     configs.set_roots(str(tmp_path), str(tmp_path / "results"))
     params = Namespace(dataset="c1", validation=True, batch_size=256, epochs=5, batch_eval=128, embed_k=32, lr=lr,
@@ -39,4 +39,4 @@ def test_c1_bprmf_metric_parity(tmp_path, opt, lr, capsys):
     for n in ("Gu", "Gi", "Bi"):
         np.testing.assert_allclose(model.engine.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1),
                                    rtol=5e-3, atol=2e-5, err_msg=n)
-    assert got["hr_t"] > 0.004                                   # learned something beyond the random-score fixture
+    assert want["hr_t"] > 0.05 and got["hr_t"] > 0.05          # ~20x the random-ranking level: the comparison is informative
