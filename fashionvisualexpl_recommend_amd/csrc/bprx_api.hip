@@ -1,5 +1,6 @@
 // bprx_api.hip -- host side of the C ABI (include/bprx.h): handle, scratch, step orchestration.
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 
 #include "bprx_internal.h"
@@ -76,7 +77,13 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     int mr = (int)((D + 127) / 128);
     h->SK = (1024 + mr - 1) / mr;
     if (h->SK > 64) h->SK = 64;
+    if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
     if (h->SK < 1) h->SK = 1;
+    if (h->SK > 256) h->SK = 256;
+    h->fwd_variant = 0;
+    h->bwd_variant = 0;
+    if (const char *e = getenv("BPRX_FWD_VARIANT")) h->fwd_variant = atoi(e);
+    if (const char *e = getenv("BPRX_BWD_VARIANT")) h->bwd_variant = atoi(e);
     A(dalloc_zero(&h->dTu, U * d));
     A(dalloc_zero(&h->P, I * PS));
     A(dalloc_zero(&h->W, I * PS));

@@ -31,6 +31,7 @@ struct bprx_handle {
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
+  int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
   // per-kernel HIP-event timing (bprx_profile_*)
   bool prof;

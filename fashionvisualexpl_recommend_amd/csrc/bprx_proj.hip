@@ -184,6 +184,194 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16(const uint16_t *__restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v2: the same tiling with software pipelining.  While chunk c is multiplied, the loads of chunk c+1
+// (A rows: HBM -> VGPR, B: L2 -> VGPR) are already in flight; B reaches LDS through a second buffer, so a
+// chunk costs ONE barrier and no wave ever waits for memory with nothing outstanding.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v2(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag) {
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BS_STRIDE];
+  constexpr int KS = KC / 32;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  // B staging: thread owns NT 16-byte pieces of the [NT*16][KC] chunk: piece t -> row n = t*16 + tid/16, k = (tid%16)*8
+  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
+  const uint16_t *bsrc = Et + (size_t)bn * D + bk;
+  uint4 breg[NT];
+  bf16x8 a_cur[KS][MT], a_nxt[KS][MT];
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_cur[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + ks * 32);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&Bs[0][(t * 16 + bn) * BS_STRIDE + bk]) = breg[t];
+  __syncthreads();
+  const int nch = D / KC;
+  for (int c = 0; c < nch; ++c) {
+    const bool more = c + 1 < nch;
+    if (more) {
+      const int k1 = (c + 1) * KC;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D + k1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_nxt[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k1 + ks * 32);
+    }
+    const uint16_t *bs = Bs[c & 1];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&bs[(nt * 16 + r) * BS_STRIDE + ks * 32 + q * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[ks][mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      uint16_t *bd = Bs[(c + 1) & 1];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&bd[(t * 16 + bn) * BS_STRIDE + bk]) = breg[t];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_cur[ks][mt] = a_nxt[ks][mt];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + mt * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward v2: MC feature columns x BTV items per tile, next tile's F rows and W rows prefetched into registers
+// while the current tile is multiplied.  `descend` walks the items from the end of the split to its start: the
+// forward pass streams F upwards, so the backward pass meets the rows the Infinity Cache still holds first.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int MC, int BTV>
+__global__ __launch_bounds__(256) void k_proj_bwd_bf16_v2(const uint16_t *__restrict__ F, int nrows, int D,
+                                                          const float *__restrict__ W, int PS, float *__restrict__ part,
+                                                          int rows_per_split, int descend) {
+  constexpr int WS = WsStride<NT>::value;
+  constexpr int FSS = MC + 16;                       // bf16 elements per LDS row of the F tile (32 B over a 256-B multiple)
+  constexpr int MTW = MC / 64;                       // 16-column M tiles per wave (4 waves)
+  constexpr int FPT = BTV * (MC / 8) / 256;          // 16-B F pieces per thread and tile
+  constexpr int WPT = (BTV * NT * 4 + 255) / 256;    // float4 W pieces per thread and tile
+  __shared__ __attribute__((aligned(16))) uint16_t Fs[BTV * FSS];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[BTV * WS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+  const int m0 = blockIdx.x * MC;
+  const int tbeg = blockIdx.y * rows_per_split;
+  int tend = tbeg + rows_per_split;
+  if (tend > nrows) tend = nrows;
+  const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 freg[FPT];
+  float4 wreg[WPT];
+  auto issue = [&](int tile) {
+    const int t0 = tbeg + (descend ? (ntiles - 1 - tile) : tile) * BTV;
+#pragma unroll
+    for (int x = 0; x < FPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / (MC / 8), ch = idx % (MC / 8), t = t0 + tr;
+      freg[x] = make_uint4(0, 0, 0, 0);
+      if (t < tend) freg[x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
+    }
+#pragma unroll
+    for (int x = 0; x < WPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / (NT * 4), c4 = idx % (NT * 4), t = t0 + tr;
+      wreg[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < BTV * NT * 4 && t < tend) wreg[x] = *reinterpret_cast<const float4 *>(W + (size_t)t * PS + c4 * 4);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int x = 0; x < FPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / (MC / 8), ch = idx % (MC / 8);
+      *reinterpret_cast<uint4 *>(&Fs[tr * FSS + ch * 8]) = freg[x];
+    }
+#pragma unroll
+    for (int x = 0; x < WPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / (NT * 4), c4 = idx % (NT * 4);
+      if (idx < BTV * NT * 4) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(wreg[x].x) | ((uint32_t)f2bf(wreg[x].y) << 16);
+        pk.y = (uint32_t)f2bf(wreg[x].z) | ((uint32_t)f2bf(wreg[x].w) << 16);
+        *reinterpret_cast<uint2 *>(&Ws[tr * WS + c4 * 4]) = pk;
+      }
+    }
+  };
+  if (ntiles > 0) issue(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();                                  // everyone is done reading the previous tile
+    commit();
+    __syncthreads();
+    if (tile + 1 < ntiles) issue(tile + 1);           // in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < BTV / 32; ++kk) {
+      bf16x8 a[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int col = (w * MTW + mt) * 16 + 4 * p;
+        bf16x4 lo = lds_tr16(&Fs[(kk * 32 + 8 * g + qq) * FSS + col]);
+        bf16x4 hi = lds_tr16(&Fs[(kk * 32 + 8 * g + qq + 4) * FSS + col]);
+        a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 16 + 4 * p;
+        bf16x4 lo = lds_tr16(&Ws[(kk * 32 + 8 * g + qq) * WS + col]);
+        bf16x4 hi = lds_tr16(&Ws[(kk * 32 + 8 * g + qq + 4) * WS + col]);
+        const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = (w * MTW + mt) * 16 + g * 4 + reg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
+    }
+}
+
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
                                                       float *__restrict__ dEp) {
@@ -230,23 +418,38 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
   }
 }
 
+#define FWD_ARGS (const uint16_t *)h->t.F, rows, (int)nrows, h->cfg.num_items, h->cfg.feat_dim, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
-  constexpr int MT = NT <= 9 ? 2 : 1;
+  constexpr int MTD = NT <= 9 ? 2 : 1;
+  // variants: 0 = v1 (2 barriers per chunk, no prefetch), 1 = v1 with one row tile per wave,
+  //           2 = v2 pipelined, 2 row tiles per wave (1 above NT 9), 3 = v2 pipelined, 1 row tile per wave
+  const int v = h->fwd_variant;
+  const int MT = (v == 1 || v == 3) ? 1 : MTD;
   const int rows_per_wg = 4 * MT * 16;
   dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
-  hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MT>), grid, dim3(256), 0, s, (const uint16_t *)h->t.F, rows, (int)nrows,
-                     h->cfg.num_items, h->cfg.feat_dim, (const uint16_t *)h->Et, Pout, h->PS, h->errflag);
+  if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
+  else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS);
+  else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
+  else hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS);
   return 0;
 }
 
 template <int NT>
 int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, I = h->cfg.num_items;
+  // variants: 0 = v1 (128 cols x 32 items, no prefetch); 1 = v2 128x32; 2 = v2 128x64; 3 = v2 64x64; +4 = descending
+  const int v = h->bwd_variant & 3, desc = (h->bwd_variant >> 2) & 1;
+  const int mc = (v == 3) ? 64 : 128;
+  const int btv = (v >= 2) ? 64 : 32;
   int rps = (I + h->SK - 1) / h->SK;
-  rps = (rps + BT - 1) / BT * BT;
-  dim3 grid(D / 128, h->SK);
-  hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, h->W, h->PS, h->part, rps);
+  rps = (rps + btv - 1) / btv * btv;
+  dim3 grid(D / mc, h->SK);
+#define BWD_ARGS (const uint16_t *)h->t.F, I, D, h->W, h->PS, h->part, rps
+  if (v == 0) hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, BWD_ARGS);
+  else if (v == 1) hipLaunchKernelGGL((k_proj_bwd_bf16_v2<NT, 128, 32>), grid, dim3(256), 0, s, BWD_ARGS, desc);
+  else if (v == 2) hipLaunchKernelGGL((k_proj_bwd_bf16_v2<NT, 128, 64>), grid, dim3(256), 0, s, BWD_ARGS, desc);
+  else hipLaunchKernelGGL((k_proj_bwd_bf16_v2<NT, 64, 64>), grid, dim3(256), 0, s, BWD_ARGS, desc);
   return 0;
 }
 

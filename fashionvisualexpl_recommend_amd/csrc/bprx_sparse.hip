@@ -157,45 +157,27 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
     atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
     a.flagU[u] = 1u; a.flagI[i] = 1u; a.flagI[j] = 1u;
   }
-  // ---- backward: per-occurrence gradients from the same pre-update rows ----
+  // ---- backward: per-occurrence gradients from the same pre-update rows (L1/L2 hits) ----
+  // Lane l of the group owns elements l, l+G, ...: every atomic wave-instruction then adds G CONTIGUOUS dwords per
+  // row (full 64-B memory-side atomic requests).  The float4 layout of the forward pass would scatter each
+  // instruction over every 4th dword and quadruple the request count (measured: 4x slower).
   float *au = a.dGu + (size_t)u * k, *ai = a.dGi + (size_t)i * k, *aj = a.dGi + (size_t)j * k;
-  if (VEC) {
-    for (int c = lane * 4; c < k; c += G * 4) {
-      float4 p = ld4(gu + c), q = ld4(gi + c), r = ld4(gj + c);
-      atomic_add4(au + c, make_float4(g * (q.x - r.x) + r2 * p.x, g * (q.y - r.y) + r2 * p.y,
-                                      g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w));
-      atomic_add4(ai + c, make_float4(g * p.x + r2 * q.x, g * p.y + r2 * q.y, g * p.z + r2 * q.z, g * p.w + r2 * q.w));
-      atomic_add4(aj + c, make_float4(-g * p.x + r2 * r.x, -g * p.y + r2 * r.y, -g * p.z + r2 * r.z, -g * p.w + r2 * r.w));
-    }
-  } else {
-    for (int c = lane; c < k; c += G) {
-      float p = gu[c], q = gi[c], r = gj[c];
-      atomicAdd(au + c, g * (q - r) + r2 * p);
-      atomicAdd(ai + c, g * p + r2 * q);
-      atomicAdd(aj + c, -g * p + r2 * r);
-    }
+  for (int c = lane; c < k; c += G) {
+    float p = gu[c], q = gi[c], r = gj[c];
+    atomicAdd(au + c, g * (q - r) + r2 * p);
+    atomicAdd(ai + c, g * p + r2 * q);
+    atomicAdd(aj + c, -g * p + r2 * r);
   }
   if (d) {
     float *at = a.dTu + (size_t)u * d;
     float *wi = a.W + (size_t)i * a.PS, *wj = a.W + (size_t)j * a.PS;
-    if (VEC) {
-      for (int c = lane * 4; c < d; c += G * 4) {
-        float4 p = ld4(tu + c), q = ld4(Pi + c), r = ld4(Pj + c);
-        atomic_add4(at + c, make_float4(g * (q.x - r.x) + r2 * p.x, g * (q.y - r.y) + r2 * p.y,
-                                        g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w));
-        float4 gp = make_float4(g * p.x, g * p.y, g * p.z, g * p.w);
-        atomic_add4(wi + c, gp);
-        atomic_add4(wj + c, make_float4(-gp.x, -gp.y, -gp.z, -gp.w));
-      }
-    } else {
-      for (int c = lane; c < d; c += G) {
-        float p = tu[c];
-        atomicAdd(at + c, g * (Pi[c] - Pj[c]) + r2 * p);
-        atomicAdd(wi + c, g * p);
-        atomicAdd(wj + c, -g * p);
-      }
+    for (int c = lane; c <= d; c += G) {                 // c == d: the Bp column of [theta_u | 1]
+      const bool last = c == d;
+      float p = last ? 1.f : tu[c];
+      if (!last) atomicAdd(at + c, g * (Pi[c] - Pj[c]) + r2 * p);
+      atomicAdd(wi + c, g * p);
+      atomicAdd(wj + c, -g * p);
     }
-    if (lane == 0) { atomicAdd(wi + d, g); atomicAdd(wj + d, -g); }     // the Bp column of [theta|1]
   }
 }
 
