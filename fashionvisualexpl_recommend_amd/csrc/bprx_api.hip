@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Ppair, h->Et, h->dEp, h->part};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -87,6 +87,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     A(dalloc_zero(&h->dTu, U * d));
     A(dalloc_zero(&h->P, I * PS));
     A(dalloc_zero(&h->W, I * PS));
+    A(dalloc_zero((uint16_t **)&h->Wb, I * PS));
     A(dalloc_zero(&h->Ppair, MB * PS));
     A(dalloc_zero((uint16_t **)&h->Et, PS * D));
     A(dalloc_zero(&h->dEp, D * d + D));

@@ -26,6 +26,7 @@ struct bprx_handle {
   int PS;                         // padded row stride of P/W/Et: 16*ceil((d+1)/16)
   float *P;                       // [I][PS]  item projections f_i.[E|Bp]
   float *W;                       // [I][PS]  sum_b +-g_b*[theta_u|1] per item; all-zero between steps
+  void *Wb;                       // bf16 [I][PS] copy of W for the backward MFMA
   float *Ppair;                   // [max_batch][PS] projections for bprx_score_pairs
   void *Et;                       // bf16 [PS][D]: [E|Bp|0]^T, refreshed every step
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)

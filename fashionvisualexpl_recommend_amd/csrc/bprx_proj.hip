@@ -372,6 +372,204 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16_v2(const uint16_t *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v3: BOTH operands staged through LDS with row-contiguous (fully coalesced) global loads -- a wave
+// instruction reads 4 rows x 256 B instead of 16 rows x 64 B in MFMA fragment order (fragment-shaped loads
+// quadruple the request count of the texture addresser; measured 2.6 TB/s).  Next chunk prefetched into
+// registers while the current one is multiplied; 288-B LDS rows make every ds_read_b128 conflict-free.
+// Workgroup = 4 waves x MT row tiles = 64*MT feature rows.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LS3 = KC + 16;   // 288-B rows: bank = 4*(2r + q) mod 64 is injective over each ds_read_b128 lane group
+
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag) {
+  constexpr int RW = 64 * MT;                       // rows per workgroup
+  constexpr int APT = RW * 16 / 256;                // 16-B A pieces per thread and chunk (= 4*MT)
+  __shared__ __attribute__((aligned(16))) uint16_t As[RW * LS3];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * LS3];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * RW;
+  // staging role: piece x -> tile row (x*16 + tid/16), 16-B chunk tid%16
+  const int sr = threadIdx.x >> 4, sc = (threadIdx.x & 15) * 8;
+  const uint16_t *asrc[APT];
+#pragma unroll
+  for (int x = 0; x < APT; ++x) {
+    int t = row0 + x * 16 + sr;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    asrc[x] = F + (size_t)item * D + sc;
+  }
+  const uint16_t *bsrc = Et + (size_t)sr * D + sc;
+  uint4 areg[APT], breg[NT];
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D);
+  const int nch = D / KC;
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();                                  // previous chunk fully consumed
+#pragma unroll
+    for (int x = 0; x < APT; ++x) *reinterpret_cast<uint4 *>(&As[(x * 16 + sr) * LS3 + sc]) = areg[x];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&Bs[(t * 16 + sr) * LS3 + sc]) = breg[t];
+    __syncthreads();
+    if (c + 1 < nch) {                                // next chunk in flight during the MFMAs
+      const int k1 = (c + 1) * KC;
+#pragma unroll
+      for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D + k1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 32) {
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        a[mt] = *reinterpret_cast<const bf16x8 *>(&As[((w * MT + mt) * 16 + r) * LS3 + ks + q * 8]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * LS3 + ks + q * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + (w * MT + mt) * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
+// Wb (bf16 [I][PS]) = W (fp32), and W is re-zeroed for the next step in the same pass.
+__global__ __launch_bounds__(256) void k_cast_W(float *__restrict__ W, uint16_t *__restrict__ Wb, size_t n4) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<float4 *>(W)[e];
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    reinterpret_cast<uint2 *>(Wb)[e] = pk;
+    reinterpret_cast<float4 *>(W)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward v3: as v2 with (a) W pre-cast to bf16 (k_cast_W) so the tile loads are plain 16-B copies, and (b) an
+// LDS image without bank conflicts for ds_read_b64_tr_b16.  One 32-lane half of a transpose read touches tile rows
+// {8g+qq} for two values of g, i.e. rows r and r+8 together: with 288-B rows (8 dwords mod 64) those alias, so rows
+// with bit 3 set are displaced by 128 B -- XOR inside the 256-B F row, an added offset inside the padded W row.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+struct WsStride3 {                     // bytes; >= NT*32 + 128 and == 32 (mod 256)
+  static constexpr int bytes = ((NT * 32 + 128 - 32 + 255) / 256) * 256 + 32;
+};
+
+template <int NT, int BTV>
+__global__ __launch_bounds__(256) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
+                                                          const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
+                                                          int rows_per_split, int descend) {
+  constexpr int FSB = 288;                           // F tile row stride, bytes (128 columns + 32)
+  constexpr int WSB = WsStride3<NT>::bytes;
+  constexpr int FPT = BTV * 16 / 256;                // 16-B F pieces per thread and tile
+  constexpr int WCH = NT * 2;                        // 16-B pieces per W row
+  constexpr int WPT = (BTV * WCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char Fs[BTV * FSB];
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[BTV * WSB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+  const int m0 = blockIdx.x * 128;
+  const int tbeg = blockIdx.y * rows_per_split;
+  int tend = tbeg + rows_per_split;
+  if (tend > nrows) tend = nrows;
+  const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 freg[FPT], wreg[WPT];
+  auto issue = [&](int tile) {
+    const int t0 = tbeg + (descend ? (ntiles - 1 - tile) : tile) * BTV;
+#pragma unroll
+    for (int x = 0; x < FPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15, t = t0 + tr;
+      freg[x] = make_uint4(0, 0, 0, 0);
+      if (t < tend) freg[x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
+    }
+#pragma unroll
+    for (int x = 0; x < WPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH, t = t0 + tr;
+      wreg[x] = make_uint4(0, 0, 0, 0);
+      if (idx < BTV * WCH && t < tend) wreg[x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int x = 0; x < FPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15;
+      *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = freg[x];
+    }
+#pragma unroll
+    for (int x = 0; x < WPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH;
+      if (idx < BTV * WCH) *reinterpret_cast<uint4 *>(&Ws[tr * WSB + ((tr & 8) << 4) + ch * 16]) = wreg[x];
+    }
+  };
+  if (ntiles > 0) issue(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + 1 < ntiles) issue(tile + 1);
+#pragma unroll
+    for (int kk = 0; kk < BTV / 32; ++kk) {
+      const int rlo = kk * 32 + 8 * g + qq, rhi = rlo + 4;       // (rlo & 8) == (rhi & 8) == 8*(g & 1)
+      const int disp = (g & 1) << 7;
+      bf16x8 a[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int cb = (((w * 2 + mt) * 16 + 4 * p) * 2) ^ disp;
+        bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rlo * FSB + cb]));
+        bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rhi * FSB + cb]));
+        a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cb = (nt * 16 + 4 * p) * 2 + disp;
+        bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rlo * WSB + cb]));
+        bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rhi * WSB + cb]));
+        const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = (w * 2 + mt) * 16 + g * 4 + reg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
+    }
+}
+
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
                                                       float *__restrict__ dEp) {
@@ -428,6 +626,13 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   const int rows_per_wg = 4 * MT * 16;
   dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
+  if (v >= 4) {   // 4 = v3 (LDS-staged A) 64 rows per workgroup, 5 = v3 128 rows per workgroup
+    const int mt3 = (v == 5 && NT <= 9) ? 2 : 1;
+    dim3 g3((unsigned)((nrows + 64 * mt3 - 1) / (64 * mt3)));
+    if (mt3 == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, (NT <= 9 ? 2 : 1)>), g3, dim3(256), 0, s, FWD_ARGS);
+    else hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, 1>), g3, dim3(256), 0, s, FWD_ARGS);
+    return 0;
+  }
   if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
   else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS);
   else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
@@ -439,7 +644,19 @@ template <int NT>
 int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, I = h->cfg.num_items;
   // variants: 0 = v1 (128 cols x 32 items, no prefetch); 1 = v2 128x32; 2 = v2 128x64; 3 = v2 64x64; +4 = descending
-  const int v = h->bwd_variant & 3, desc = (h->bwd_variant >> 2) & 1;
+  const int desc = (h->bwd_variant >> 2) & 1;
+  if (h->bwd_variant >= 8) {   // 8 = v3 128 cols x 32 items, 9 = v3 128 x 64 (+4 = descending)
+    const int v3 = h->bwd_variant & 3, bt3 = v3 == 1 ? 64 : 32;
+    int rps3 = (I + h->SK - 1) / h->SK;
+    rps3 = (rps3 + bt3 - 1) / bt3 * bt3;
+    const size_t n4 = (size_t)I * h->PS / 4;
+    hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
+    dim3 g3(D / 128, h->SK);
+    if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
+    else hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 64>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
+    return 0;
+  }
+  const int v = h->bwd_variant & 3;
   const int mc = (v == 3) ? 64 : 128;
   const int btv = (v >= 2) ? 64 : 32;
   int rps = (I + h->SK - 1) / h->SK;
