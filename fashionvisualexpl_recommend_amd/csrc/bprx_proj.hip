@@ -42,11 +42,15 @@ constexpr int BS_STRIDE = KC + 8;  // bf16 elements; 272-B rows keep ds_read_b12
 template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                        int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                       float *__restrict__ P, int PS, int32_t *errflag) {
+                                                       float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
   __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * BS_STRIDE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  // Every workgroup walks the same [E|Bp]^T chunks; started together they would all hit the same few L2 lines
+  // at the same moment.  `stagger` rotates the chunk order per workgroup (only the fp32 summation order changes).
+  const int nchunks = D / KC;
+  const int cshift = stagger ? (int)((blockIdx.x * 5u) % (unsigned)nchunks) : 0;
   const uint16_t *arow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -62,7 +66,10 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < D; k0 += KC) {
+  for (int cc = 0; cc < nchunks; ++cc) {
+    int ce = cc + cshift;
+    if (ce >= nchunks) ce -= nchunks;
+    const int k0 = ce * KC;
     __syncthreads();
     for (int idx = threadIdx.x; idx < NT * 16 * (KC / 8); idx += 256) {
       const int n = idx / (KC / 8), kk = (idx % (KC / 8)) * 8;
@@ -385,7 +392,7 @@ constexpr int LS3 = KC + 16;   // 288-B rows: bank = 4*(2r + q) mod 64 is inject
 template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                           int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag) {
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
   constexpr int RW = 64 * MT;                       // rows per workgroup
   constexpr int APT = RW * 16 / 256;                // 16-B A pieces per thread and chunk (= 4*MT)
   __shared__ __attribute__((aligned(16))) uint16_t As[RW * LS3];
@@ -411,11 +418,16 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__rest
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x]);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D);
   const int nch = D / KC;
+  const int cshift = stagger ? (int)((blockIdx.x * 5u) % (unsigned)nch) : 0;   // see k_proj_fwd_bf16
+  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
+  {
+    const int k1 = kof(0);
+#pragma unroll
+    for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D + k1);
+  }
   for (int c = 0; c < nch; ++c) {
     __syncthreads();                                  // previous chunk fully consumed
 #pragma unroll
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__rest
     for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&Bs[(t * 16 + sr) * LS3 + sc]) = breg[t];
     __syncthreads();
     if (c + 1 < nch) {                                // next chunk in flight during the MFMAs
-      const int k1 = (c + 1) * KC;
+      const int k1 = kof(c + 1);
 #pragma unroll
       for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
 #pragma unroll
@@ -622,19 +634,19 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   constexpr int MTD = NT <= 9 ? 2 : 1;
   // variants: 0 = v1 (2 barriers per chunk, no prefetch), 1 = v1 with one row tile per wave,
   //           2 = v2 pipelined, 2 row tiles per wave (1 above NT 9), 3 = v2 pipelined, 1 row tile per wave
-  const int v = h->fwd_variant;
+  const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3) & 1;   // +8 = staggered chunk order (v1 / v3)
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   const int rows_per_wg = 4 * MT * 16;
   dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
   if (v >= 4) {   // 4 = v3 (LDS-staged A) 64 rows per workgroup, 5 = v3 128 rows per workgroup
     const int mt3 = (v == 5 && NT <= 9) ? 2 : 1;
     dim3 g3((unsigned)((nrows + 64 * mt3 - 1) / (64 * mt3)));
-    if (mt3 == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, (NT <= 9 ? 2 : 1)>), g3, dim3(256), 0, s, FWD_ARGS);
-    else hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, 1>), g3, dim3(256), 0, s, FWD_ARGS);
+    if (mt3 == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, (NT <= 9 ? 2 : 1)>), g3, dim3(256), 0, s, FWD_ARGS, stg);
+    else hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, 1>), g3, dim3(256), 0, s, FWD_ARGS, stg);
     return 0;
   }
-  if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
-  else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS);
+  if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+  else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
   else hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS);
   return 0;
