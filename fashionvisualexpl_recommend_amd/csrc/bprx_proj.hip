@@ -582,6 +582,187 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16_v3(const uint16_t *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v4.  Measured on v1-v3: these kernels are LATENCY-bound, not bandwidth-bound -- a workgroup has one
+// k-chunk of its rows in flight per memory round trip (~4.7 us under load), so the chip moves
+// (resident rows x chunk bytes) per round trip: 50K rows x 256 B = 12.8 MB -> 2.7 TB/s.  v4 widens the chunk to
+// KCV = 256 columns (512 B per row, 16 loads in flight per wave) and issues the [E|Bp]^T chunk and the feature-row
+// chunk TOGETHER, so one round trip serves both.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int MT, int KCV>
+__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v4(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
+  constexpr int BSS = KCV + 16;                      // 32-B pad: conflict-free ds_read_b128 (see LS3)
+  constexpr int KS = KCV / 32;
+  constexpr int LPR = KCV / 8;                       // 16-B pieces per staged B row
+  constexpr int BPT = NT * 16 * LPR / 256;           // pieces per thread
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * BSS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  const int bn = threadIdx.x / LPR, bk = (threadIdx.x % LPR) * 8;     // piece x -> B row bn + x*(256/LPR)
+  constexpr int BROWS = 256 / LPR;
+  const uint16_t *bsrc = Et + (size_t)bn * D + bk;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nch = D / KCV;
+  const int cshift = stagger ? (int)((blockIdx.x * 5u) % (unsigned)nch) : 0;
+  for (int c = 0; c < nch; ++c) {
+    int ce = c + cshift;
+    if (ce >= nch) ce -= nch;
+    const int k0 = ce * KCV;
+    uint4 breg[BPT];
+    bf16x8 a[KS][MT];
+#pragma unroll
+    for (int x = 0; x < BPT; ++x) breg[x] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)x * BROWS * D + k0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k0 + ks * 32);
+    __syncthreads();                                  // previous chunk's B fully consumed
+#pragma unroll
+    for (int x = 0; x < BPT; ++x) *reinterpret_cast<uint4 *>(&Bs[(bn + x * BROWS) * BSS + bk]) = breg[x];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * BSS + ks * 32 + q * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][mt], b, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + mt * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward v4: v3 with TWO item tiles in flight per workgroup (two named register sets; the commit of tile t only
+// waits for its own loads because vmcnt retires in issue order, so tile t+1 stays in flight across the barriers).
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_proj_bwd_bf16_v4(const uint16_t *__restrict__ F, int nrows, int D,
+                                                          const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
+                                                          int rows_per_split, int descend) {
+  constexpr int BTV = 32;
+  constexpr int FSB = 288;
+  constexpr int WSB = WsStride3<NT>::bytes;
+  constexpr int FPT = BTV * 16 / 256;                // 2
+  constexpr int WCH = NT * 2;
+  constexpr int WPT = (BTV * WCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char Fs[BTV * FSB];
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[BTV * WSB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+  const int m0 = blockIdx.x * 128;
+  const int tbeg = blockIdx.y * rows_per_split;
+  int tend = tbeg + rows_per_split;
+  if (tend > nrows) tend = nrows;
+  const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 fX[FPT], wX[WPT], fY[FPT], wY[WPT];
+  auto issue = [&](int tile, uint4 (&fr)[FPT], uint4 (&wr)[WPT]) {
+    const int t0 = tbeg + (descend ? (ntiles - 1 - tile) : tile) * BTV;
+#pragma unroll
+    for (int x = 0; x < FPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15, t = t0 + tr;
+      fr[x] = make_uint4(0, 0, 0, 0);
+      if (tile < ntiles && t < tend) fr[x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
+    }
+#pragma unroll
+    for (int x = 0; x < WPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH, t = t0 + tr;
+      wr[x] = make_uint4(0, 0, 0, 0);
+      if (tile < ntiles && idx < BTV * WCH && t < tend) wr[x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);
+    }
+  };
+  auto commit = [&](uint4 (&fr)[FPT], uint4 (&wr)[WPT]) {
+#pragma unroll
+    for (int x = 0; x < FPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15;
+      *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = fr[x];
+    }
+#pragma unroll
+    for (int x = 0; x < WPT; ++x) {
+      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH;
+      if (idx < BTV * WCH) *reinterpret_cast<uint4 *>(&Ws[tr * WSB + ((tr & 8) << 4) + ch * 16]) = wr[x];
+    }
+  };
+  auto compute = [&]() {
+    const int rlo = 8 * g + qq, rhi = rlo + 4;
+    const int disp = (g & 1) << 7;
+    bf16x8 a[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int cb = (((w * 2 + mt) * 16 + 4 * p) * 2) ^ disp;
+      bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rlo * FSB + cb]));
+      bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rhi * FSB + cb]));
+      a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cb = (nt * 16 + 4 * p) * 2 + disp;
+      bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rlo * WSB + cb]));
+      bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rhi * WSB + cb]));
+      const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+    }
+  };
+  issue(0, fX, wX);
+  issue(1, fY, wY);
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    __syncthreads();
+    commit(fX, wX);
+    __syncthreads();
+    issue(tile + 2, fX, wX);
+    compute();
+    if (tile + 1 < ntiles) {
+      __syncthreads();
+      commit(fY, wY);
+      __syncthreads();
+      issue(tile + 3, fY, wY);
+      compute();
+    }
+  }
+  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = (w * 2 + mt) * 16 + g * 4 + reg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
+    }
+}
+
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
                                                       float *__restrict__ dEp) {
@@ -638,6 +819,21 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   const int rows_per_wg = 4 * MT * 16;
   dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
+  if (v >= 6) {   // 6 = v4 KC 256, 2 row tiles per wave (1 above NT 9); 7 = v4 KC 256, 1 row tile per wave
+    if (h->cfg.feat_dim % 256 == 0) {
+      constexpr int MT4 = NT <= 9 ? 2 : 1;
+      if (v == 6) {
+        dim3 g4((unsigned)((nrows + 64 * MT4 - 1) / (64 * MT4)));
+        hipLaunchKernelGGL((k_proj_fwd_bf16_v4<NT, MT4, 256>), g4, dim3(256), 0, s, FWD_ARGS, stg);
+      } else {
+        dim3 g4((unsigned)((nrows + 63) / 64));
+        hipLaunchKernelGGL((k_proj_fwd_bf16_v4<NT, 1, 256>), g4, dim3(256), 0, s, FWD_ARGS, stg);
+      }
+      return 0;
+    }
+    hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+    return 0;
+  }
   if (v >= 4) {   // 4 = v3 (LDS-staged A) 64 rows per workgroup, 5 = v3 128 rows per workgroup
     const int mt3 = (v == 5 && NT <= 9) ? 2 : 1;
     dim3 g3((unsigned)((nrows + 64 * mt3 - 1) / (64 * mt3)));
@@ -657,14 +853,15 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, I = h->cfg.num_items;
   // variants: 0 = v1 (128 cols x 32 items, no prefetch); 1 = v2 128x32; 2 = v2 128x64; 3 = v2 64x64; +4 = descending
   const int desc = (h->bwd_variant >> 2) & 1;
-  if (h->bwd_variant >= 8) {   // 8 = v3 128 cols x 32 items, 9 = v3 128 x 64 (+4 = descending)
+  if (h->bwd_variant >= 8) {   // 8 = v3 128 cols x 32 items, 9 = v3 128 x 64, 10 = v4 (two tiles in flight) (+4 = descending)
     const int v3 = h->bwd_variant & 3, bt3 = v3 == 1 ? 64 : 32;
     int rps3 = (I + h->SK - 1) / h->SK;
     rps3 = (rps3 + bt3 - 1) / bt3 * bt3;
     const size_t n4 = (size_t)I * h->PS / 4;
     hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
     dim3 g3(D / 128, h->SK);
-    if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
+    if (v3 == 2) hipLaunchKernelGGL((k_proj_bwd_bf16_v4<NT>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
+    else if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
     else hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 64>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
     return 0;
   }
