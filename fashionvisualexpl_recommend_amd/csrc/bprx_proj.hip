@@ -21,14 +21,19 @@ __device__ __forceinline__ uint16_t f2bf(float x) {   // round-to-nearest-even; 
   return (uint16_t)(u >> 16);
 }
 
-// Et[n][k] (bf16, [PS][D]) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.   One thread per (n, k).
+// [E|Bp|0]^T in bf16, stored CHUNK-MAJOR: element (n, k) at ((k/128)*PS + n)*128 + k%128, i.e. each 128-wide k-chunk
+// of all PS rows is one contiguous PS*256-byte block.  (A plain [PS][D] image has 8-KB rows: the rows of one chunk
+// then sit at a power-of-two stride and every workgroup's chunk load lands on the same few L2 channels.)
+__device__ __forceinline__ size_t et_idx(int n, int k, int PS) { return ((size_t)(k >> 7) * PS + n) * 128 + (k & 127); }
+
+// Et(n, k) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.   One thread per (n, k).
 __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, const float *__restrict__ Bp,
                                                  uint16_t *__restrict__ Et, int D, int d, int PS) {
   const int kk = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (kk >= D) return;
   float v = n < d ? E[(size_t)kk * d + n] : (n == d ? Bp[kk] : 0.f);
-  Et[(size_t)n * D + kk] = f2bf(v);
+  Et[et_idx(n, kk, PS)] = f2bf(v);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -50,7 +55,8 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
   // Every workgroup walks the same [E|Bp]^T chunks; started together they would all hit the same few L2 lines
   // at the same moment.  `stagger` rotates the chunk order per workgroup (only the fp32 summation order changes).
   const int nchunks = D / KC;
-  const int cshift = stagger ? (int)((blockIdx.x * 5u) % (unsigned)nchunks) : 0;
+  const int cshift = (stagger & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nchunks) : 0;
+  const bool dbg_skip_b = stagger & 2, dbg_skip_a = stagger & 4;   // timing-only ablations (wrong results)
   const uint16_t *arow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -71,16 +77,17 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
     if (ce >= nchunks) ce -= nchunks;
     const int k0 = ce * KC;
     __syncthreads();
+    if (!(dbg_skip_b && cc > 0))
     for (int idx = threadIdx.x; idx < NT * 16 * (KC / 8); idx += 256) {
       const int n = idx / (KC / 8), kk = (idx % (KC / 8)) * 8;
-      *reinterpret_cast<uint4 *>(&Bs[n * BS_STRIDE + kk]) = *reinterpret_cast<const uint4 *>(&Et[(size_t)n * D + k0 + kk]);
+      *reinterpret_cast<uint4 *>(&Bs[n * BS_STRIDE + kk]) = *reinterpret_cast<const uint4 *>(&Et[et_idx(n, k0 + kk, NT * 16)]);
     }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KC; ks += 32) {
       bf16x8 a[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k0 + ks);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + ((dbg_skip_a && cc > 0) ? 0 : k0) + ks);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * BS_STRIDE + ks + q * 8]);
@@ -217,7 +224,6 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v2(const uint16_t *__rest
   }
   // B staging: thread owns NT 16-byte pieces of the [NT*16][KC] chunk: piece t -> row n = t*16 + tid/16, k = (tid%16)*8
   const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
-  const uint16_t *bsrc = Et + (size_t)bn * D + bk;
   uint4 breg[NT];
   bf16x8 a_cur[KS][MT], a_nxt[KS][MT];
   f32x4 acc[MT][NT];
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v2(const uint16_t *__rest
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D);
+  for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + bn, bk, NT * 16)]);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v2(const uint16_t *__rest
     if (more) {
       const int k1 = (c + 1) * KC;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D + k1);
+      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -411,7 +417,6 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__rest
     if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
     asrc[x] = F + (size_t)item * D + sc;
   }
-  const uint16_t *bsrc = Et + (size_t)sr * D + sc;
   uint4 areg[APT], breg[NT];
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -419,14 +424,14 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__rest
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nch = D / KC;
-  const int cshift = stagger ? (int)((blockIdx.x * 5u) % (unsigned)nch) : 0;   // see k_proj_fwd_bf16
+  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;   // see k_proj_fwd_bf16
   auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
   {
     const int k1 = kof(0);
 #pragma unroll
     for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D + k1);
+    for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + sr, k1 + sc, NT * 16)]);
   }
   for (int c = 0; c < nch; ++c) {
     __syncthreads();                                  // previous chunk fully consumed
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__rest
 #pragma unroll
       for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)t * 16 * D + k1);
+      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + sr, k1 + sc, NT * 16)]);
     }
 #pragma unroll
     for (int ks = 0; ks < KC; ks += 32) {
@@ -613,14 +618,13 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v4(const uint16_t *__rest
   }
   const int bn = threadIdx.x / LPR, bk = (threadIdx.x % LPR) * 8;     // piece x -> B row bn + x*(256/LPR)
   constexpr int BROWS = 256 / LPR;
-  const uint16_t *bsrc = Et + (size_t)bn * D + bk;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nch = D / KCV;
-  const int cshift = stagger ? (int)((blockIdx.x * 5u) % (unsigned)nch) : 0;
+  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
   for (int c = 0; c < nch; ++c) {
     int ce = c + cshift;
     if (ce >= nch) ce -= nch;
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v4(const uint16_t *__rest
     uint4 breg[BPT];
     bf16x8 a[KS][MT];
 #pragma unroll
-    for (int x = 0; x < BPT; ++x) breg[x] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)x * BROWS * D + k0);
+    for (int x = 0; x < BPT; ++x) breg[x] = *reinterpret_cast<const uint4 *>(&Et[et_idx(bn + x * BROWS, k0 + bk, NT * 16)]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -815,7 +819,7 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   constexpr int MTD = NT <= 9 ? 2 : 1;
   // variants: 0 = v1 (2 barriers per chunk, no prefetch), 1 = v1 with one row tile per wave,
   //           2 = v2 pipelined, 2 row tiles per wave (1 above NT 9), 3 = v2 pipelined, 1 row tile per wave
-  const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3) & 1;   // +8 = staggered chunk order (v1 / v3)
+  const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3);   // +8 = staggered chunk order (v1 / v3 / v4); +16/+32: v1 ablations
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   const int rows_per_wg = 4 * MT * 16;
   dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
