@@ -663,6 +663,212 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16_v4(const uint16_t *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v5: explicit ping-pong software pipeline (two named register sets, loop unrolled by two, scheduling
+// fences between the phases) -- the v2 source was "un-pipelined" by the compiler (its MFMAs waited on the loads
+// issued in the same iteration).  Per chunk: [issue loads of chunk c+1 into the idle set] -> [MFMA chunk c from
+// the live set + LDS] -> [park chunk c+1's B rows in the other LDS buffer] -> ONE barrier.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v5(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
+  constexpr int BSS = KC + 16;
+  constexpr int KS = KC / 32;
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
+  const int nch = D / KC;
+  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
+  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 bX[NT], bY[NT];
+  bf16x8 aX[KS][MT], aY[KS][MT];
+  // (macros, not lambdas: register arrays passed by reference ended up in scratch memory)
+#define V5_ISSUE(c_, BR, AR)                                                                                          \
+  {                                                                                                                   \
+    const int k1 = kof(c_);                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
+        BR[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);                         \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        AR[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k1 + ks * 32);                                      \
+  }
+#define V5_PARK(buf_, BR)                                                                                             \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
+        *reinterpret_cast<uint4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
+  }
+#define V5_COMPUTE(buf_, AR)                                                                                          \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][(nt * 16 + r) * BSS + ks * 32 + q * 8]);         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AR[ks][mt], b, acc[mt][nt], 0, 0, 0);               \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  V5_ISSUE(0, bX, aX)
+  V5_PARK(0, bX)
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {            // nch is even (D % 256 == 0 is required by the launcher)
+    V5_ISSUE(c + 1, bY, aY)
+    __builtin_amdgcn_sched_barrier(0);
+    V5_COMPUTE(0, aX)
+    __builtin_amdgcn_sched_barrier(0);
+    V5_PARK(1, bY)
+    __syncthreads();
+    if (c + 2 < nch) V5_ISSUE(c + 2, bX, aX)
+    __builtin_amdgcn_sched_barrier(0);
+    V5_COMPUTE(1, aY)
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < nch) V5_PARK(0, bX)
+    __syncthreads();
+  }
+#undef V5_ISSUE
+#undef V5_PARK
+#undef V5_COMPUTE
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + mt * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v6: the v5 ping-pong pipeline with its global loads and waits written as inline asm.  hipcc kept
+// re-timing the C++ version (it sank the [E|Bp]^T loads next to their LDS store and waited on same-iteration loads
+// inside the MFMA block), so every chunk still paid a full memory round trip.  Here every loop load is an asm
+// `global_load_dwordx4`; the compiler sees no VMEM event, inserts no vmcnt of its own, and the two counted waits per
+// half-iteration are placed by hand (vmcnt retires in issue order: B pieces first, then the A fragments):
+//   before parking chunk c+1's B pieces:  vmcnt(KS*MT)        -> only the A fragments of c+1 stay in flight
+//   before the MFMAs of chunk c:          vmcnt(NT + KS*MT)   -> everything of c+1 stays in flight
+// Each register is then passed through an empty asm ("+v") so no use can be scheduled above its wait.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ void asm_gload(i32x4 &dst, const void *p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void asm_tie(i32x4 &r) { asm volatile("" : "+v"(r)); }
+
+template <int NT, int MT>
+__global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
+  constexpr int BSS = KC + 16;
+  constexpr int KS = KC / 32;
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
+  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
+  const int nch = D / KC;
+  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
+  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4 bX[NT], bY[NT], aX[KS][MT], aY[KS][MT];
+#define V6_ISSUE(c_, BR, AR)                                                                                          \
+  {                                                                                                                   \
+    const int k1 = kof(c_);                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);      \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
+  }
+#define V6_PARK(buf_, BR, NWAIT)                                                                                      \
+  {                                                                                                                   \
+    asm_vmcnt<NWAIT>();                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_tie(BR[t]);                                                    \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
+        *reinterpret_cast<i32x4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
+  }
+#define V6_COMPUTE(buf_, AR, NWAIT)                                                                                   \
+  {                                                                                                                   \
+    asm_vmcnt<NWAIT>();                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        asm_tie(AR[ks][mt]);                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][(nt * 16 + r) * BSS + ks * 32 + q * 8]);         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[ks][mt]), b,          \
+                                                                 acc[mt][nt], 0, 0, 0);                               \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  constexpr int NA = KS * MT, NALL = NT + KS * MT;
+  V6_ISSUE(0, bX, aX)
+  V6_PARK(0, bX, NA)
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {            // nch is even (D % 256 == 0 is required by the launcher)
+    V6_ISSUE(c + 1, bY, aY)
+    V6_COMPUTE(0, aX, NALL)
+    V6_PARK(1, bY, NA)
+    __syncthreads();
+    if (c + 2 < nch) {
+      V6_ISSUE(c + 2, bX, aX)
+      V6_COMPUTE(1, aY, NALL)
+      V6_PARK(0, bX, NA)
+    } else {
+      V6_COMPUTE(1, aY, 0)
+    }
+    __syncthreads();
+  }
+#undef V6_ISSUE
+#undef V6_PARK
+#undef V6_COMPUTE
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + mt * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // backward v4: v3 with TWO item tiles in flight per workgroup (two named register sets; the commit of tile t only
 // waits for its own loads because vmcnt retires in issue order, so tile t+1 stays in flight across the barriers).
@@ -847,8 +1053,9 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   }
   if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-  else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS);
-  else hipLaunchKernelGGL((k_proj_fwd_bf16_v2<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS);
+  else if (h->cfg.feat_dim % 256 != 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), dim3((unsigned)((nrows + 4 * MTD * 16 - 1) / (4 * MTD * 16))), dim3(256), 0, s, FWD_ARGS, stg);
+  else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+  else hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   return 0;
 }
 
