@@ -840,20 +840,25 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
   V6_ISSUE(0, bX, aX)
   V6_PARK(0, bX, NA)
   __syncthreads();
+  // No branch may separate an asm load from its wait: at a control-flow join the compiler is free to copy what it
+  // believes are finished values (observed: v_mov of in-flight registers in an else-branch -> garbage).  The loop
+  // body is therefore straight-line; the last prefetch re-reads chunk nch-1 instead of being skipped.
   for (int c = 0; c < nch; c += 2) {            // nch is even (D % 256 == 0 is required by the launcher)
     V6_ISSUE(c + 1, bY, aY)
     V6_COMPUTE(0, aX, NALL)
     V6_PARK(1, bY, NA)
     __syncthreads();
-    if (c + 2 < nch) {
-      V6_ISSUE(c + 2, bX, aX)
-      V6_COMPUTE(1, aY, NALL)
-      V6_PARK(0, bX, NA)
-    } else {
-      V6_COMPUTE(1, aY, 0)
-    }
+    const int cn = c + 2 < nch ? c + 2 : nch - 1;
+    V6_ISSUE(cn, bX, aX)
+    V6_COMPUTE(1, aY, NALL)
+    V6_PARK(0, bX, NA)
     __syncthreads();
   }
+  asm_vmcnt<0>();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm_tie(aX[ks][mt]);
 #undef V6_ISSUE
 #undef V6_PARK
 #undef V6_COMPUTE
