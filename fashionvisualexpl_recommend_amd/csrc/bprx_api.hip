@@ -80,8 +80,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
     if (h->SK < 1) h->SK = 1;
     if (h->SK > 256) h->SK = 256;
-    h->fwd_variant = 0;
-    h->bwd_variant = 0;
+    // defaults = the fastest measured variants (profiles/r01_sweeps.md): forward v6 (asm-pinned ping-pong pipeline,
+    // staggered chunk order; falls back to v1 when D % 256 != 0), backward v3 (bf16 W, conflict-free LDS image).
+    h->fwd_variant = 10;
+    h->bwd_variant = 8;
     if (const char *e = getenv("BPRX_FWD_VARIANT")) h->fwd_variant = atoi(e);
     if (const char *e = getenv("BPRX_BWD_VARIANT")) h->bwd_variant = atoi(e);
     A(dalloc_zero(&h->dTu, U * d));

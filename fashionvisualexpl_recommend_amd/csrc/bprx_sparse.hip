@@ -385,7 +385,9 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   const bool vec = vec_ok(h);
   const int G = pick_group(a.k, a.d, vec);
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
-  if (a.d) BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
+  // W must be all-zero here: k_cast_W (backward variants >= 8) re-zeroes it while converting; other variants don't
+  if (a.d && (h->bwd_variant < 8 || h->cfg.feat_dtype != BPRX_F_BF16))
+    BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
   return BPRX_OK;

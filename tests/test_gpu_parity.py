@@ -41,7 +41,14 @@ def _dev(a):
     return torch.as_tensor(a, device="cuda")
 
 
-def _close(got, want, rtol, atol, msg=""):
+def _close(got, want, rtol, atol, msg="", outlier_frac=0.0, outlier_abs=0.0):
+    """allclose; optionally a fraction `outlier_frac` of elements may miss it by up to `outlier_abs` (Adam's first
+    steps are sign-like: an element whose tiny gradient flips sign under bf16 rounding moves by ~2*lr)."""
+    if outlier_frac:
+        bad = np.abs(got - want) > atol + rtol * np.abs(want)
+        assert bad.mean() <= outlier_frac, "%s: %.4f%% outside tolerance" % (msg, 100 * bad.mean())
+        assert np.abs(got - want).max() <= outlier_abs, "%s: max abs diff %g" % (msg, np.abs(got - want).max())
+        return
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=msg)
 
 
@@ -153,6 +160,7 @@ def test_vbpr_steps_match_oracle(k, d, D, dtype, opt, reg):
         loss = e.step(_dev(u), _dev(i), _dev(j)).item()
         want = o.step(u, i, j, opt, lr, reg)
         assert loss == pytest.approx(want, rel=1e-4 if bf else 2e-5)
+        of, oa = (1e-3, 3 * lr) if (bf and opt != "sgd") else (0.0, 0.0)
         for n in ("Gu", "Gi", "Bi", "Tu", "E", "Bp"):
-            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step))
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step), of, oa)
     e.sync_check()
