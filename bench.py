@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam_tf23"])
+    ap.add_argument("--sampler", default="philox", choices=["philox", "pregen"],
+                    help="philox: device sampler inside the timed step; pregen: resident pre-generated index batches")
+    ap.add_argument("--pos-per-user", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
     return ap.parse_args()
@@ -117,14 +120,25 @@ def main():
 
     gi = torch.Generator(device=device)
     gi.manual_seed(99 + rank)
-    nb = min(K + W, 16)                                   # distinct resident index batches, cycled
-    batches = [(torch.randint(w["U"], (B,), generator=gi, device=device, dtype=torch.int32),
-                torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32),
-                torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32)) for _ in range(nb)]
+    if args.sampler == "philox":
+        # synthetic training interactions resident in HBM: pos-per-user uniform items per user, CSR sorted per user
+        from fashionvisualexpl_recommend_amd.engine import PhiloxSampler
+        npu = args.pos_per_user
+        items = torch.randint(w["I"], (w["U"], npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
+        indptr = torch.arange(w["U"] + 1, device=device, dtype=torch.int64) * npu
+        pos_user = torch.arange(w["U"], device=device, dtype=torch.int32).repeat_interleave(npu)
+        sampler = PhiloxSampler.from_csr(indptr, items.reshape(-1), pos_user, w["I"], seed=2024 + rank)
+        bufs = tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3))
+        batches, nb = None, 0
+    else:
+        nb = min(K + W, 16)                               # distinct resident index batches, cycled
+        batches = [(torch.randint(w["U"], (B,), generator=gi, device=device, dtype=torch.int32),
+                    torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32),
+                    torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32)) for _ in range(nb)]
     dense = eng.dense_grad() if (world > 1 and w["model"] == "vbpr") else None
 
     def one_step(s):
-        u, i, j = batches[s % nb]
+        u, i, j = sampler.sample(B, out=bufs) if batches is None else batches[s % nb]
         if dense is None:
             eng.step(u, i, j, want_loss=False)
         else:
@@ -158,7 +172,7 @@ def main():
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile(False)
-    loss = float(eng.step(*batches[0]).item())           # sanity: the path produced a finite loss
+    loss = float(eng.step(*(sampler.sample(B, out=bufs) if batches is None else batches[0])).item())  # sanity: finite loss
     assert np.isfinite(loss), loss
 
     if rank == 0:
@@ -191,7 +205,8 @@ def main():
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
                                       w["dtype"], B, args.optimizer),
                        "global_batch": B * world, "parallelism": "item-shard x%d, all-reduce(E|Bp)" % world if world > 1 else "single",
-                       "sampler": "pre-generated uniform (u,i,j), resident"},
+                       "sampler": ("device philox, uniform positive + rejection negative, inside the timed step (%d positives/user)"
+                                   % args.pos_per_user) if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,
             "step_roofline": {"bytes_per_triplet": per_trip, "achieved": value * per_trip / 1e9 / world,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value * per_trip / 1e9 / world / HBM_PEAK_GBS},

@@ -75,6 +75,7 @@ def lib():
         "bprx_sync_check": (C.c_int, [vp, vp]),
         "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
         "bprx_profile_read": (C.c_int, [vp, vp, vp]),
+        "bprx_sample_philox": (C.c_int, [vp, vp, vp, i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp, vp, vp]),
         "bprx_sampler_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "bprx_sampler_destroy": (C.c_int, [vp]),
         "bprx_sampler_count": (i64, [vp, i32, i32]),
@@ -92,7 +93,7 @@ def lib():
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_dense_grad", "bprx_step_end", "bprx_score_block", "bprx_sync_check", "bprx_profile_enable",
-           "bprx_profile_read", "bprx_sampler_create",
+           "bprx_profile_read", "bprx_sample_philox", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]
 
 

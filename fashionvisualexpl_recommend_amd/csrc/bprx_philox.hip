@@ -1,0 +1,69 @@
+// bprx_philox.hip -- device-side throughput sampler (replaces the role of
+// DataLoader.all_triple_batches, dataset.py:83-114, when bit-compatibility with the reference's MT19937 stream
+// is not required).  Counter-based Philox4x32-10: triplet n of stream `seed` is a pure function of (seed, n):
+//   block(n, a) = philox(key = seed, ctr = (n_lo, n_hi, a, 0))
+//   positive p  = mulhi64(block(n,0).xy, N)  -> (pos_user[p], items_sorted[p])   uniform over training interactions
+//   negative j  = mulhi32(block(n,a).z, I), a = 0,1,.. until j is not a positive of the user (binary search in the
+//                 user's ascending item list; at most 64 attempts)                uniform over non-positives
+// so any rank can regenerate any other rank's triplets, and the CPU twin (oracle/bpr_oracle.c orc_sample_philox)
+// is bit-exact.  One thread per triplet; 12 B written per triplet.
+#include <hip/hip_runtime.h>
+
+#include "bprx.h"
+
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict__ indptr, const int32_t *__restrict__ items,
+                                                       const int32_t *__restrict__ pos_user, unsigned long long N, uint32_t I,
+                                                       uint32_t k0, uint32_t k1, unsigned long long first, long long B,
+                                                       int32_t *__restrict__ u, int32_t *__restrict__ i, int32_t *__restrict__ j) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const unsigned long long n = first + (unsigned long long)b;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, k0, k1, r);
+  const unsigned long long x = ((unsigned long long)r[1] << 32) | r[0];
+  const unsigned long long p = __umul64hi(x, N);
+  const int32_t uu = pos_user[p];
+  const long long lo0 = indptr[uu], len = indptr[uu + 1] - lo0;
+  const int32_t *lst = items + lo0;
+  int32_t jj = 0;
+  for (uint32_t a = 0; a < 64u; ++a) {
+    if (a) philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), a, 0u, k0, k1, r);
+    jj = (int32_t)__umulhi(r[2], I);
+    long long lo = 0, hi = len;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (lst[mid] < jj) lo = mid + 1; else hi = mid;
+    }
+    if (!(lo < len && lst[lo] == jj)) break;
+  }
+  u[b] = uu; i[b] = items[p]; j[b] = jj;
+}
+
+}  // namespace
+
+extern "C" int bprx_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user,
+                                  int64_t num_pos, int32_t num_items, uint64_t seed, uint64_t first, int64_t B,
+                                  int32_t *user, int32_t *pos, int32_t *neg, void *stream) {
+  if (!indptr || !items_sorted || !pos_user || !user || !pos || !neg || num_pos <= 0 || num_items <= 0 || B < 0)
+    return BPRX_E_INVALID;
+  if (B == 0) return BPRX_OK;
+  hipLaunchKernelGGL(k_sample_philox, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
+                     items_sorted, pos_user, (unsigned long long)num_pos, (uint32_t)num_items, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (unsigned long long)first, (long long)B, user, pos, neg);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}

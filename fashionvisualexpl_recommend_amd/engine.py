@@ -168,6 +168,44 @@ class _DevView:
         self.tensor = torch.as_tensor(self, device=device)
 
 
+class PhiloxSampler:
+    """bprx_sample_philox: device-side stateless throughput sampler over a CSR of training interactions."""
+
+    def __init__(self, train_lists, num_items, device=None, seed=0):
+        self.lib = _ffi.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        indptr = np.zeros(len(train_lists) + 1, dtype=np.int64)
+        for u, l in enumerate(train_lists):
+            indptr[u + 1] = indptr[u] + len(l)
+        items = np.fromiter((i for l in train_lists for i in sorted(l)), dtype=np.int32, count=int(indptr[-1]))
+        pos_user = np.repeat(np.arange(len(train_lists), dtype=np.int32), np.diff(indptr))
+        self.num_pos, self.num_items, self.seed, self.next = int(indptr[-1]), int(num_items), int(seed), 0
+        if self.num_pos == 0:
+            raise ValueError("no training interactions")
+        self.indptr, self.items, self.pos_user = (torch.as_tensor(a, device=self.device) for a in (indptr, items, pos_user))
+
+    @classmethod
+    def from_csr(cls, indptr, items_sorted, pos_user, num_items, seed=0):
+        """Device tensors: indptr int64 [U+1], items_sorted int32 [N] (ascending inside each user), pos_user int32 [N]."""
+        self = cls.__new__(cls)
+        self.lib = _ffi.lib()
+        self.device = indptr.device
+        self.indptr, self.items, self.pos_user = indptr.contiguous(), items_sorted.contiguous(), pos_user.contiguous()
+        self.num_pos, self.num_items, self.seed, self.next = int(items_sorted.numel()), int(num_items), int(seed), 0
+        return self
+
+    def sample(self, B, first=None, out=None):
+        """B triplets starting at stream position `first` (default: continue).  Returns int32 device tensors."""
+        if first is None:
+            first, self.next = self.next, self.next + B
+        u, i, j = out if out is not None else tuple(torch.empty(B, dtype=torch.int32, device=self.device) for _ in range(3))
+        rc = self.lib.bprx_sample_philox(_ptr(self.indptr), _ptr(self.items), _ptr(self.pos_user), self.num_pos,
+                                         self.num_items, self.seed, first, B, _ptr(u), _ptr(i), _ptr(j), _stream())
+        if rc < 0:
+            raise _ffi.BprxError(rc, "bprx_sample_philox failed")
+        return u, i, j
+
+
 class HostSampler:
     """bprx_sampler_*: the reference-compatible host index stream (dataset.py:83-114)."""
 

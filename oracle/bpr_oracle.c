@@ -508,3 +508,46 @@ void orc_set_threads(int n) {
   (void)n;
 #endif
 }
+
+/* ------------------------------------------------------------------------- */
+/* Throughput sampler twin (NOT in the reference: SURVEY 8(f) N2).             */
+/* Counter-based Philox4x32-10: triplet n of stream `seed` is a pure function  */
+/* of (seed, n), so the device kernel and this loop produce the same triplets. */
+/*   block(n, a) = philox(key = seed, ctr = (n_lo, n_hi, a, 0))                */
+/*   positive p  = mulhi64(block(n,0).xy, N)          -> (user_of[p], item_of[p]) */
+/*   negative j  = mulhi32(block(n,a).z, I), a = 0,1,.. until j not in train(u) */
+/*   (train lists sorted ascending per user; at most 64 attempts).             */
+/* ------------------------------------------------------------------------- */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user, int64_t N,
+                       int32_t I, uint64_t seed, uint64_t first, int64_t B, int32_t *u, int32_t *i, int32_t *j) {
+  for (int64_t b = 0; b < B; b++) {
+    uint64_t n = first + (uint64_t)b;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0, 0, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    uint64_t x = ((uint64_t)r[1] << 32) | r[0];
+    uint64_t p = (uint64_t)(((unsigned __int128)x * (unsigned __int128)(uint64_t)N) >> 64);
+    int32_t uu = pos_user[p];
+    const int32_t *lst = items_sorted + indptr[uu];
+    int64_t len = indptr[uu + 1] - indptr[uu];
+    int32_t jj = 0;
+    for (uint32_t a = 0; a < 64; a++) {
+      if (a) philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), a, 0, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      jj = (int32_t)(((uint64_t)r[2] * (uint64_t)(uint32_t)I) >> 32);
+      int64_t lo = 0, hi = len;                     /* binary search in the sorted positives */
+      while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (lst[mid] < jj) lo = mid + 1; else hi = mid; }
+      if (!(lo < len && lst[lo] == jj)) break;
+    }
+    u[b] = uu; i[b] = items_sorted[p]; j[b] = jj;
+  }
+}

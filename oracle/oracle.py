@@ -55,6 +55,8 @@ def lib():
                                C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.orc_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_sample_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint64,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bf16_round.restype = C.c_float
         L.orc_bf16_round.argtypes = [C.c_float]
         L.orc_num_threads.restype = C.c_int
@@ -85,6 +87,23 @@ def sample_ref_stream(train_lists, num_items, batch_size, epochs, py_seed=0, np_
     got = lib().orc_sample_ref_stream(_p(indptr), _p(items), U, num_items, batch_size, epochs,
                                       py_seed, np_seed, _p(u), _p(i), _p(j), n)
     assert got == n, (got, n)
+    return u, i, j
+
+
+def interactions_csr(train_lists):
+    """(indptr int64 [U+1], items int32 sorted ascending per user, pos_user int32 [N]) -- the philox sampler's inputs."""
+    indptr = np.zeros(len(train_lists) + 1, dtype=np.int64)
+    for u, l in enumerate(train_lists):
+        indptr[u + 1] = indptr[u] + len(l)
+    items = np.fromiter((i for l in train_lists for i in sorted(l)), dtype=np.int32, count=int(indptr[-1]))
+    pos_user = np.repeat(np.arange(len(train_lists), dtype=np.int32), np.diff(indptr))
+    return indptr, items, pos_user
+
+
+def sample_philox(train_lists, num_items, seed, first, B):
+    indptr, items, pos_user = interactions_csr(train_lists)
+    u = np.empty(B, np.int32); i = np.empty(B, np.int32); j = np.empty(B, np.int32)
+    lib().orc_sample_philox(_p(indptr), _p(items), _p(pos_user), len(items), num_items, seed, first, B, _p(u), _p(i), _p(j))
     return u, i, j
 
 

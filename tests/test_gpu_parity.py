@@ -164,3 +164,18 @@ def test_vbpr_steps_match_oracle(k, d, D, dtype, opt, reg):
         for n in ("Gu", "Gi", "Bi", "Tu", "E", "Bp"):
             _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step), of, oa)
     e.sync_check()
+
+
+def test_philox_sampler_bit_exact_vs_cpu_twin():
+    from fashionvisualexpl_recommend_amd.engine import PhiloxSampler
+    tr, _, _ = synth.make_interactions(300, 180, per_user=22, seed=3)
+    tr[7] = list(range(170))                       # a user whose positives cover almost every item: many rejections
+    s = PhiloxSampler(tr, 180, seed=0xDEADBEEF12345)
+    u, i, j = (t.cpu().numpy() for t in s.sample(50000))
+    wu, wi, wj = orc.sample_philox(tr, 180, 0xDEADBEEF12345, 0, 50000)
+    assert np.array_equal(u, wu) and np.array_equal(i, wi) and np.array_equal(j, wj)
+    u2, i2, j2 = (t.cpu().numpy() for t in s.sample(1000, first=2 ** 33 + 5))   # 64-bit counters
+    wu, wi, wj = orc.sample_philox(tr, 180, 0xDEADBEEF12345, 2 ** 33 + 5, 1000)
+    assert np.array_equal(u2, wu) and np.array_equal(i2, wi) and np.array_equal(j2, wj)
+    for a, b, c in zip(u[:5000], i[:5000], j[:5000]):
+        assert b in tr[a] and c not in tr[a]

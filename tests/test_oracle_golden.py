@@ -102,3 +102,17 @@ def test_eval_c1(golden_dir):
     got = orc.evaluate(sc, tr, va, te, want["K"])
     for k in KEYS:
         assert got[k] == pytest.approx(want["results"][k], abs=1e-12), k
+
+
+def test_philox_twin_properties():
+    """The throughput sampler is not in the reference; its CPU twin must at least be a valid BPR sampler:
+    positives are training interactions, negatives are not, any slice of the stream is reproducible."""
+    tr, _, _ = synth.make_interactions(120, 90, per_user=12, seed=5)
+    u, i, j = orc.sample_philox(tr, 90, 42, 0, 30000)
+    for a, b, c in zip(u, i, j):
+        assert b in tr[a] and c not in tr[a] and 0 <= c < 90
+    u2, i2, j2 = orc.sample_philox(tr, 90, 42, 12345, 100)
+    assert np.array_equal(u2, u[12345:12445]) and np.array_equal(j2, j[12345:12445])
+    cnt = np.bincount(u, minlength=120)              # every user has 10 positives -> uniform over users
+    assert cnt.min() > 150 and cnt.max() < 350
+    assert not np.array_equal(orc.sample_philox(tr, 90, 43, 0, 100)[2], j[:100])
