@@ -68,7 +68,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   A(dalloc_zero(&h->flagU, U));
   A(dalloc_zero(&h->flagI, I));
   A(dalloc_zero(&h->lossb, MB));
-  A(dalloc_zero(&h->loss_acc, (size_t)4));
+  A(dalloc_zero(&h->loss_acc, (size_t)BPRX_DENSE_BLOCKS));
   A(dalloc_zero(&h->errflag, (size_t)1));
   if (vb) {
     h->PS = 16 * (int)((d + 1 + 15) / 16);
@@ -202,7 +202,6 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
-  BPRX_HIP(h, hipMemsetAsync(h->loss_acc, 0, 4 * sizeof(double), s));
   if (vb) {
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
@@ -247,9 +246,12 @@ extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
 
 extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
                          float *loss_out, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  h->fused_reduce = true;          // no all-reduce in between: the dense update sums the split-K slabs itself
   int rc = bprx_step_begin(h, user, pos, neg, B, stream);
-  if (rc) return rc;
-  return bprx_step_end(h, loss_out, stream);
+  if (!rc) rc = bprx_step_end(h, loss_out, stream);
+  h->fused_reduce = false;
+  return rc;
 }
 
 extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream) {

@@ -9,6 +9,8 @@
 
 #include "bprx.h"
 
+#define BPRX_DENSE_BLOCKS 512
+
 struct bprx_handle {
   bprx_config cfg;
   bprx_tables t;
@@ -20,7 +22,9 @@ struct bprx_handle {
   float *dGu, *dGi, *dBi, *dTu;   // dense fp32 gradient staging, same shapes as the tables; all-zero between steps
   uint32_t *flagU, *flagI;        // "row touched this step" marks (sgd claim)
   float *lossb;                   // [max_batch] per-triplet loss (data + per-occurrence regularisation)
-  double *loss_acc;               // [4] scalars: [0] sum(lossb) [1] ||E||^2+||Bp||^2
+  double *loss_acc;               // [BPRX_DENSE_BLOCKS] per-block partial sums of ||E||^2+||Bp||^2 (k_dense_update)
+  int dense_blocks;               // blocks of the last k_dense_update launch
+  bool fused_reduce;              // bprx_step: k_dense_update sums the split-K slabs itself (no k_reduce_parts)
   int32_t *errflag;               // device-side deferred error (index out of range)
   // VBPR projection state
   int PS;                         // padded row stride of P/W/Et: 16*ceil((d+1)/16)

@@ -4,7 +4,7 @@
 //   block(n, a) = philox(key = seed, ctr = (n_lo, n_hi, a, 0))
 //   positive p  = mulhi64(block(n,0).xy, N)  -> (pos_user[p], items_sorted[p])   uniform over training interactions
 //   negative j  = mulhi32(block(n,a).z, I), a = 0,1,.. until j is not a positive of the user (binary search in the
-//                 user's ascending item list; at most 64 attempts)                uniform over non-positives
+//                 user's ascending item list; at most 1024 attempts)              uniform over non-positives
 // so any rank can regenerate any other rank's triplets, and the CPU twin (oracle/bpr_oracle.c orc_sample_philox)
 // is bit-exact.  One thread per triplet; 12 B written per triplet.
 #include <hip/hip_runtime.h>
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict
   const long long lo0 = indptr[uu], len = indptr[uu + 1] - lo0;
   const int32_t *lst = items + lo0;
   int32_t jj = 0;
-  for (uint32_t a = 0; a < 64u; ++a) {
+  for (uint32_t a = 0; a < 1024u; ++a) {
     if (a) philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), a, 0u, k0, k1, r);
     jj = (int32_t)__umulhi(r[2], I);
     long long lo = 0, hi = len;

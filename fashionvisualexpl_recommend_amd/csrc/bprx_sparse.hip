@@ -248,31 +248,43 @@ __global__ void k_clear_flags(uint32_t *f, size_t n) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) f[e] = 0u;
 }
 
-// Dense shared parameters E [D,d] and Bp [D]: grad = dEp (+ all-reduced) + 2*reg*param, then sgd or the
-// dense ApplyAdam rule  m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)   (VBPR.py:142).
-// Also accumulates ||E||^2+||Bp||^2 (pre-update) for the loss (VBPR.py:127).
+// Dense shared parameters E [D,d] and Bp [D]: grad = (sum of the SK split-K slabs of the backward projection, or the
+// all-reduced dEp) + 2*reg*param, then sgd or the dense ApplyAdam rule
+//   m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)                      (VBPR.py:142).
+// One thread per (k, n) of the padded [D][PS] slab layout (n <= d used).  ||E||^2+||Bp||^2 (pre-update, VBPR.py:127)
+// leaves as one double per block in sqpart[] (summed in fixed order by k_loss_reduce: no atomics, reproducible).
 __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, float *__restrict__ Bp, float *mE, float *vE,
-                                                      float *mBp, float *vBp, const float *__restrict__ dEp, size_t nE,
-                                                      size_t nB, int adam, float lr_t, float reg, float b1, float b2,
-                                                      float eps, double *loss_acc) {
+                                                      float *mBp, float *vBp, const float *__restrict__ dEp,
+                                                      const float *__restrict__ part, int SK, int D, int d, int PS, int adam,
+                                                      float lr_t, float reg, float b1, float b2, float eps,
+                                                      double *__restrict__ sqpart) {
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   double sq = 0.0;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nE + nB; e += (size_t)gridDim.x * blockDim.x) {
-    float *p = e < nE ? E + e : Bp + (e - nE);
-    float pv = *p;
+  const size_t total = (size_t)D * PS;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e / PS), n = (int)(e % PS);
+    if (n > d) continue;
+    float gsum;
+    if (part) {                                        // fused split-K reduction (single-GPU step), fixed slab order
+      gsum = 0.f;
+      for (int sidx = 0; sidx < SK; ++sidx) gsum += part[(size_t)sidx * total + e];
+    } else {
+      gsum = n < d ? dEp[(size_t)kk * d + n] : dEp[(size_t)D * d + kk];
+    }
+    float *p = n < d ? E + (size_t)kk * d + n : Bp + kk;
+    const float pv = *p;
     sq += (double)pv * (double)pv;
-    float gg = dEp[e] + 2.f * reg * pv;
+    const float gg = gsum + 2.f * reg * pv;
     if (adam) {
-      float *m = e < nE ? mE + e : mBp + (e - nE), *v = e < nE ? vE + e : vBp + (e - nE);
-      float mt = *m + (gg - *m) * omb1;
-      float vt = *v + (gg * gg - *v) * omb2;
+      float *m = n < d ? mE + (size_t)kk * d + n : mBp + kk, *v = n < d ? vE + (size_t)kk * d + n : vBp + kk;
+      const float mt = *m + (gg - *m) * omb1;
+      const float vt = *v + (gg * gg - *v) * omb2;
       *m = mt; *v = vt;
       *p = pv - lr_t * mt / (sqrtf(vt) + eps);
     } else {
       *p = pv - lr_t * gg;
     }
   }
-  // block reduction of sq -> one double atomic per block (a few hundred per step)
   __shared__ double red[256];
   red[threadIdx.x] = sq;
   __syncthreads();
@@ -280,25 +292,24 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(loss_acc + 1, red[0]);
+  if (threadIdx.x == 0) sqpart[blockIdx.x] = red[0];
 }
 
 // loss = sum_b lossb[b] + reg*(||E||^2+||Bp||^2); fixed summation order (one block), double accumulation.
-__global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ lossb, int64_t B, double *loss_acc,
-                                                      float reg, float *__restrict__ out) {
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ lossb, int64_t B,
+                                                      const double *__restrict__ sqpart, int nsq, float reg,
+                                                      float *__restrict__ out) {
   __shared__ double red[1024];
   double s = 0.0;
   for (int64_t b = threadIdx.x; b < B; b += 1024) s += (double)lossb[b];
+  for (int q = threadIdx.x; q < nsq; q += 1024) s += (double)reg * sqpart[q];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    *out = (float)(red[0] + (double)reg * loss_acc[1]);
-    loss_acc[1] = 0.0;
-  }
+  if (threadIdx.x == 0) *out = (float)red[0];
 }
 
 // predict_all rows [u0,u1): out[u-u0][i] = Bi[i] + <Gu[u],Gi[i]> (+ <Tu[u],P_i[0:d]> + P_i[d]).
@@ -422,20 +433,25 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
 }
 
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
-  const size_t nE = (size_t)h->cfg.feat_dim * h->cfg.embed_d, nB = h->cfg.feat_dim;
-  unsigned blocks = (unsigned)((nE + nB + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
+  const size_t total = (size_t)h->cfg.feat_dim * h->PS;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > BPRX_DENSE_BLOCKS) blocks = BPRX_DENSE_BLOCKS;
+  h->dense_blocks = (int)blocks;
   BprxProfScope ps(h, BPRX_PHASE_DENSE, s);
+  // fused_reduce: the split-K slabs are summed here (bprx_step); otherwise dEp holds the (all-reduced) gradient
+  const float *part = h->fused_reduce ? h->part : nullptr;
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
-                     h->t.v_Bp, h->dEp, nE, nB, h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg,
-                     h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->loss_acc);
+                     h->t.v_Bp, h->dEp, part, h->SK, h->cfg.feat_dim, h->cfg.embed_d, h->PS,
+                     h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg, h->cfg.beta1, h->cfg.beta2,
+                     h->cfg.epsilon, h->loss_acc);
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
   return BPRX_OK;
 }
 
 int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStream_t s) {
   BprxProfScope ps(h, BPRX_PHASE_LOSS, s);
-  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, h->lossb, B, h->loss_acc, h->cfg.reg, loss_out);
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, h->lossb, B, h->loss_acc,
+                     h->cfg.model == BPRX_MODEL_VBPR ? h->dense_blocks : 0, h->cfg.reg, loss_out);
   BPRX_LAUNCH_CHECK(h, "k_loss_reduce");
   return BPRX_OK;
 }

@@ -145,7 +145,7 @@ BPRX_API int64_t bprx_sampler_ref_stream(bprx_sampler *s, int32_t batch_size, in
 /* ---- throughput sampler (DEVICE side; not in the reference: its sampler tops out at ~4e5 triplets/s) ---------
    Stateless counter-based Philox4x32-10: triplet n = first + b of stream `seed` depends on (seed, n) only.
    Positive: uniform over the num_pos training interactions (pos_user[p], items_sorted[p]); negative: uniform over the
-   items that are not positives of that user (rejection with binary search, <= 64 attempts).  Replaces the role of
+   items that are not positives of that user (rejection with binary search, <= 1024 attempts).  Replaces the role of
    dataset.py:83-122 for throughput runs; its distribution differs from the reference's epoch-permutation walk.
    All pointers are DEVICE pointers: indptr int64 [U+1], items_sorted int32 [num_pos] (ascending inside each user),
    pos_user int32 [num_pos]. */

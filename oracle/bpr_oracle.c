@@ -516,7 +516,7 @@ void orc_set_threads(int n) {
 /*   block(n, a) = philox(key = seed, ctr = (n_lo, n_hi, a, 0))                */
 /*   positive p  = mulhi64(block(n,0).xy, N)          -> (user_of[p], item_of[p]) */
 /*   negative j  = mulhi32(block(n,a).z, I), a = 0,1,.. until j not in train(u) */
-/*   (train lists sorted ascending per user; at most 64 attempts).             */
+/*   (train lists sorted ascending per user; at most 1024 attempts).             */
 /* ------------------------------------------------------------------------- */
 static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
   for (int r = 0; r < 10; r++) {
@@ -541,7 +541,7 @@ void orc_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const
     const int32_t *lst = items_sorted + indptr[uu];
     int64_t len = indptr[uu + 1] - indptr[uu];
     int32_t jj = 0;
-    for (uint32_t a = 0; a < 64; a++) {
+    for (uint32_t a = 0; a < 1024; a++) {
       if (a) philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), a, 0, (uint32_t)seed, (uint32_t)(seed >> 32), r);
       jj = (int32_t)(((uint64_t)r[2] * (uint64_t)(uint32_t)I) >> 32);
       int64_t lo = 0, hi = len;                     /* binary search in the sorted positives */
