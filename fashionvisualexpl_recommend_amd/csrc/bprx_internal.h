@@ -9,7 +9,7 @@
 
 #include "bprx.h"
 
-#define BPRX_DENSE_BLOCKS 512
+#define BPRX_DENSE_BLOCKS 2048
 
 struct bprx_handle {
   bprx_config cfg;

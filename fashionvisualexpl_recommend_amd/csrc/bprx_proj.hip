@@ -26,25 +26,22 @@ __device__ __forceinline__ uint16_t f2bf(float x) {   // round-to-nearest-even; 
 // then sit at a power-of-two stride and every workgroup's chunk load lands on the same few L2 channels.)
 __device__ __forceinline__ size_t et_idx(int n, int k, int PS) { return ((size_t)(k >> 7) * PS + n) * 128 + (k & 127); }
 
-// Et(n, k) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.  One block per 64-row k-tile: E rows are read coalesced
-// (n fastest), transposed through LDS, and every Et row segment is written as 128 contiguous bytes.
+// Et(n, k) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.  One block per (64 k-rows x 16 columns) tile, transposed
+// through LDS so that every Et row segment is written as 128 contiguous bytes.
 __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, const float *__restrict__ Bp,
                                                  uint16_t *__restrict__ Et, int D, int d, int PS) {
-  __shared__ float tile[64][65];
-  const int k0 = blockIdx.x * 64;
-  for (int n0 = 0; n0 < PS; n0 += 64) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-      const int kr = idx >> 6, nc = idx & 63, kk = k0 + kr, n = n0 + nc;
-      float v = 0.f;
-      if (kk < D) v = n < d ? E[(size_t)kk * d + n] : (n == d ? Bp[kk] : 0.f);
-      tile[kr][nc] = v;
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-      const int nc = idx >> 6, kr = idx & 63, kk = k0 + kr, n = n0 + nc;
-      if (n < PS && kk < D) Et[et_idx(n, kk, PS)] = f2bf(tile[kr][nc]);
-    }
+  __shared__ float tile[64][17];
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
+  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+    const int kr = idx >> 4, nc = idx & 15, kk = k0 + kr, n = n0 + nc;
+    float v = 0.f;
+    if (kk < D) v = n < d ? E[(size_t)kk * d + n] : (n == d ? Bp[kk] : 0.f);
+    tile[kr][nc] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+    const int nc = idx >> 6, kr = idx & 63, kk = k0 + kr, n = n0 + nc;
+    if (n < PS && kk < D) Et[et_idx(n, kk, PS)] = f2bf(tile[kr][nc]);
   }
 }
 
@@ -1134,7 +1131,7 @@ int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
   if (h->cfg.feat_dtype != BPRX_F_BF16) return BPRX_OK;
   const int D = h->cfg.feat_dim;
   BprxProfScope ps(h, BPRX_PHASE_CAST_ET, s);
-  dim3 grid((D + 63) / 64);
+  dim3 grid((D + 63) / 64, h->PS / 16);
   hipLaunchKernelGGL(k_cast_Et, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint16_t *)h->Et, D, h->cfg.embed_d, h->PS);
   BPRX_LAUNCH_CHECK(h, "k_cast_Et");
   return BPRX_OK;
@@ -1169,7 +1166,7 @@ int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s) {
 #undef CALL
     }
     BPRX_LAUNCH_CHECK(h, "k_proj_bwd_bf16");
-    if (h->fused_reduce) return BPRX_OK;              // k_dense_update sums the slabs (bprx_step)
+    if (h->fused_reduce) return BPRX_OK;              // k_dense_update sums the slabs (bprx_step, bf16 path)
     const size_t n = (size_t)D * h->PS;
     BprxProfScope ps(h, BPRX_PHASE_REDUCE, s);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK, D, d, h->PS, h->dEp);

@@ -267,7 +267,15 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     float gsum;
     if (part) {                                        // fused split-K reduction (single-GPU step), fixed slab order
       gsum = 0.f;
-      for (int sidx = 0; sidx < SK; ++sidx) gsum += part[(size_t)sidx * total + e];
+      int sidx = 0;
+      for (; sidx + 8 <= SK; sidx += 8) {              // 8 independent loads in flight, then a fixed-order sum
+        float t[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) t[x] = part[(size_t)(sidx + x) * total + e];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) gsum += t[x];
+      }
+      for (; sidx < SK; ++sidx) gsum += part[(size_t)sidx * total + e];
     } else {
       gsum = n < d ? dEp[(size_t)kk * d + n] : dEp[(size_t)D * d + kk];
     }
@@ -439,7 +447,7 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   h->dense_blocks = (int)blocks;
   BprxProfScope ps(h, BPRX_PHASE_DENSE, s);
   // fused_reduce: the split-K slabs are summed here (bprx_step); otherwise dEp holds the (all-reduced) gradient
-  const float *part = h->fused_reduce ? h->part : nullptr;
+  const float *part = (h->fused_reduce && h->cfg.feat_dtype == BPRX_F_BF16) ? h->part : nullptr;
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
                      h->t.v_Bp, h->dEp, part, h->SK, h->cfg.feat_dim, h->cfg.embed_d, h->PS,
                      h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg, h->cfg.beta1, h->cfg.beta2,
