@@ -107,16 +107,28 @@ def main():
         w["B"] = args.batch
     B, K, W = w["B"], args.steps, args.warmup
 
-    # Weak scaling: every rank holds one shard of this shape (item + user shard, item-sharded VBPR); the dense
-    # shared parameters E|Bp are kept identical on all ranks by an RCCL all-reduce of their gradient every step.
-    # Round 1: each rank's synthetic triplets reference its own user shard (no user-row exchange yet).
+    # Weak scaling: every rank holds one item shard + one user shard of this shape.  N > 1 (VBPR): item-sharded step
+    # of fashionvisualexpl_recommend_amd/dist.py -- users of a rank's batch are GLOBAL (any shard): their rows are
+    # fetched / their gradients returned by all-to-all, E|Bp gradients are all-reduced (RCCL), negatives stay local.
     tables = make_state(w, device, 1234 + rank, torch)
+    sharded = None
+    users_total = w["U"] * world
     if world > 1 and w["model"] == "vbpr":
         for n in ("E", "Bp"):
             dist.broadcast(tables[n], src=0)
-    eng = Engine(model=w["model"], num_users=w["U"], num_items=w["I"], embed_k=w["k"], embed_d=w["d"], feat_dim=w["D"],
-                 feat_dtype=w["dtype"], optimizer=args.optimizer, lr=0.05, reg=1e-4, max_batch=B,
-                 device=local_rank).bind(**tables)
+        if args.optimizer != "sgd":
+            raise SystemExit("multi-GPU bench supports --optimizer sgd")
+        from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
+        sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
+                                  tables["F"], tables["E"], tables["Bp"], lr=0.05, reg=1e-4, max_batch=B,
+                                  feat_dtype=w["dtype"], device=local_rank)
+        eng = sharded.eng
+    else:
+        if world > 1:
+            raise SystemExit("multi-GPU bench is implemented for the VBPR workloads")
+        eng = Engine(model=w["model"], num_users=w["U"], num_items=w["I"], embed_k=w["k"], embed_d=w["d"],
+                     feat_dim=w["D"], feat_dtype=w["dtype"], optimizer=args.optimizer, lr=0.05, reg=1e-4, max_batch=B,
+                     device=local_rank).bind(**tables)
 
     gi = torch.Generator(device=device)
     gi.manual_seed(99 + rank)
@@ -124,27 +136,24 @@ def main():
         # synthetic training interactions resident in HBM: pos-per-user uniform items per user, CSR sorted per user
         from fashionvisualexpl_recommend_amd.engine import PhiloxSampler
         npu = args.pos_per_user
-        items = torch.randint(w["I"], (w["U"], npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
-        indptr = torch.arange(w["U"] + 1, device=device, dtype=torch.int64) * npu
-        pos_user = torch.arange(w["U"], device=device, dtype=torch.int32).repeat_interleave(npu)
+        # (N > 1: every GLOBAL user has pos-per-user positives inside this rank's item shard)
+        items = torch.randint(w["I"], (users_total, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
+        indptr = torch.arange(users_total + 1, device=device, dtype=torch.int64) * npu
+        pos_user = torch.arange(users_total, device=device, dtype=torch.int32).repeat_interleave(npu)
         sampler = PhiloxSampler.from_csr(indptr, items.reshape(-1), pos_user, w["I"], seed=2024 + rank)
         bufs = tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3))
         batches, nb = None, 0
     else:
         nb = min(K + W, 16)                               # distinct resident index batches, cycled
-        batches = [(torch.randint(w["U"], (B,), generator=gi, device=device, dtype=torch.int32),
+        batches = [(torch.randint(users_total, (B,), generator=gi, device=device, dtype=torch.int32),
                     torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32),
                     torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32)) for _ in range(nb)]
-    dense = eng.dense_grad() if (world > 1 and w["model"] == "vbpr") else None
-
     def one_step(s):
         u, i, j = sampler.sample(B, out=bufs) if batches is None else batches[s % nb]
-        if dense is None:
+        if sharded is None:
             eng.step(u, i, j, want_loss=False)
         else:
-            eng.step_begin(u, i, j)
-            dist.all_reduce(dense)                        # RCCL over xGMI, same stream
-            eng.step_end(want_loss=False)
+            sharded.step(u, i, j)                         # all-to-all user rows, all-reduce E|Bp grads (RCCL over xGMI)
 
     def barrier():
         if world > 1:
@@ -172,7 +181,8 @@ def main():
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile(False)
-    loss = float(eng.step(*(sampler.sample(B, out=bufs) if batches is None else batches[0])).item())  # sanity: finite loss
+    ub, ib, jb = sampler.sample(B, out=bufs) if batches is None else batches[0]
+    loss = float((eng.step(ub, ib, jb) if sharded is None else sharded.step(ub, ib, jb, want_loss=True)).item())
     assert np.isfinite(loss), loss
 
     if rank == 0:
@@ -204,7 +214,7 @@ def main():
             "config": {"workload": "%s: %s k=%d d=%d D=%d, %d users x %d items per GPU, %s features, B=%d per GPU, %s"
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
                                       w["dtype"], B, args.optimizer),
-                       "global_batch": B * world, "parallelism": "item-shard x%d, all-reduce(E|Bp)" % world if world > 1 else "single",
+                       "global_batch": B * world, "parallelism": ("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world) if world > 1 else "single",
                        "sampler": ("device philox, uniform positive + rejection negative, inside the timed step (%d positives/user)"
                                    % args.pos_per_user) if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,

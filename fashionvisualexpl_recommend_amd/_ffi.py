@@ -9,7 +9,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbprx.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
+FLAG_EXPORT_USER_GRAD = 1
 
 MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
@@ -29,7 +30,7 @@ class Config(C.Structure):
                 ("embed_k", C.c_int32), ("embed_d", C.c_int32), ("feat_dim", C.c_int32), ("feat_dtype", C.c_int32),
                 ("optimizer", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int64),
                 ("lr", C.c_float), ("reg", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("epsilon", C.c_float)]
+                ("epsilon", C.c_float), ("flags", C.c_int32)]
 
 
 TABLE_FIELDS = ["Gu", "Gi", "Bi", "Tu", "F", "E", "Bp", "m_Gu", "v_Gu", "m_Gi", "v_Gi", "m_Bi", "v_Bi",
@@ -71,6 +72,10 @@ def lib():
         "bprx_step_begin": (C.c_int, [vp, vp, vp, vp, i64, vp]),
         "bprx_dense_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "bprx_step_end": (C.c_int, [vp, vp, vp]),
+        "bprx_step_project": (C.c_int, [vp, vp]),
+        "bprx_user_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "bprx_clear_user_grad": (C.c_int, [vp, i64, vp]),
+        "bprx_scatter_add": (C.c_int, [vp, i32, i32, vp, vp, i64, f32, vp]),
         "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
         "bprx_sync_check": (C.c_int, [vp, vp]),
         "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -92,7 +97,8 @@ def lib():
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
-           "bprx_dense_grad", "bprx_step_end", "bprx_score_block", "bprx_sync_check", "bprx_profile_enable",
+           "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad",
+           "bprx_scatter_add", "bprx_score_block", "bprx_sync_check", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]
 

@@ -50,6 +50,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (cfg->feat_dtype == BPRX_F_BF16 && cfg->feat_dim % 128 != 0)
       CFAIL(BPRX_E_INVALID, "bf16 features need feat_dim %% 128 == 0 (got %d)", cfg->feat_dim);
   }
+  if ((cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) && cfg->optimizer != BPRX_OPT_SGD)
+    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_USER_GRAD supports optimizer sgd only");
   hipError_t e = hipSetDevice(cfg->device);
   if (e != hipSuccess) CFAIL(BPRX_E_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
 
@@ -202,10 +204,11 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
-  if (vb) {
+  if (vb && !h->proj_fresh) {
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
   }
+  h->proj_fresh = false;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;                              // dE|dBp = F^T W
   // sparse tables are final now: apply their optimizer (does not depend on the dense all-reduce)
@@ -217,6 +220,33 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   }
   if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, s))) return rc;
   h->pending_B = B;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_step_project(bprx_handle *h, void *stream) {
+  int rc = check_ready(h, 0);
+  if (rc) return rc;
+  if (h->cfg.model != BPRX_MODEL_VBPR) return BPRX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = bprx_launch_cast_Et(h, s))) return rc;
+  if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;
+  h->proj_fresh = true;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_user_grad(bprx_handle *h, float **dGu, float **dTu) {
+  if (!h || !dGu || !dTu) return BPRX_E_INVALID;
+  *dGu = h->dGu;
+  *dTu = h->dTu;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream) {
+  if (!h || n_rows < 0 || n_rows > h->cfg.num_users) return BPRX_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  BPRX_HIP(h, hipMemsetAsync(h->dGu, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
+  if (h->cfg.embed_d) BPRX_HIP(h, hipMemsetAsync(h->dTu, 0, (size_t)n_rows * h->cfg.embed_d * sizeof(float), s));
+  BPRX_HIP(h, hipMemsetAsync(h->flagU, 0, (size_t)n_rows * sizeof(uint32_t), s));
   return BPRX_OK;
 }
 

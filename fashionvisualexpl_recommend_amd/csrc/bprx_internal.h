@@ -24,6 +24,7 @@ struct bprx_handle {
   float *lossb;                   // [max_batch] per-triplet loss (data + per-occurrence regularisation)
   double *loss_acc;               // [BPRX_DENSE_BLOCKS] per-block partial sums of ||E||^2+||Bp||^2 (k_dense_update)
   int dense_blocks;               // blocks of the last k_dense_update launch
+  bool proj_fresh;                // bprx_step_project already ran for the coming step
   bool fused_reduce;              // bprx_step: k_dense_update sums the split-K slabs itself (no k_reduce_parts)
   int32_t *errflag;               // device-side deferred error (index out of range)
   // VBPR projection state

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *Bi, float *Tu, SparseArgs a,
                                                    const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
-                                                   const int32_t *__restrict__ neg, int64_t B, float lr) {
-  const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+                                                   const int32_t *__restrict__ neg, int64_t B, float lr, int first_kind) {
+  const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G + (int64_t)first_kind * B;
   const int lane = threadIdx.x % G;
   if (job >= 3 * B) return;
   const int kind = (int)(job / B);
@@ -389,6 +389,31 @@ inline dim3 grid_for(int64_t groups, int G) {
 
 }  // namespace
 
+// table[idx[r], :] += scale * rows[r, :]   (owner-side application of routed gradient rows; lane = element, so each
+// atomic wave-instruction adds contiguous dwords)
+__global__ __launch_bounds__(256) void k_scatter_add(float *__restrict__ table, int num_rows, int ncols,
+                                                     const int32_t *__restrict__ idx, const float *__restrict__ rows,
+                                                     int64_t n, float scale) {
+  const int64_t total = n * ncols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / ncols;
+    const int c = (int)(e - r * ncols);
+    const int row = idx[r];
+    if ((unsigned)row < (unsigned)num_rows) atomicAdd(table + (size_t)row * ncols + c, scale * rows[e]);
+  }
+}
+
+extern "C" int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,
+                                int64_t n, float scale, void *stream) {
+  if (!table || !idx || !rows || num_rows <= 0 || num_cols <= 0 || n < 0) return BPRX_E_INVALID;
+  if (n == 0) return BPRX_OK;
+  int64_t blocks = (n * num_cols + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, num_rows, num_cols, idx,
+                     rows, n, scale);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}
+
 int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_t B, const float *Prow, int p_by_pair,
                       float *x, hipStream_t s) {
   SparseArgs a = make_args(h, h->cfg.embed_d ? (p_by_pair ? Prow : h->P) : nullptr);
@@ -419,7 +444,9 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
   if (h->cfg.optimizer == BPRX_OPT_SGD) {
     const bool vec = vec_ok(h);
     const int G = pick_group(a.k, a.d, vec);
-    DISPATCH_G(G, vec, k_apply_sgd, grid_for(3 * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B, lr_t);
+    // first_kind = 1 skips the user rows (their gradients are exported to the caller: BPRX_FLAG_EXPORT_USER_GRAD)
+    const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
+    DISPATCH_G(G, vec, k_apply_sgd, grid_for((3 - fk) * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B, lr_t, fk);
     BPRX_LAUNCH_CHECK(h, "k_apply_sgd");
     return BPRX_OK;
   }

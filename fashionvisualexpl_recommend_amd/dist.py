@@ -1,0 +1,119 @@
+"""Item-sharded multi-GPU VBPR (BASELINE.json configs[3]): one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm).
+
+Partitioning
+  items  range-partitioned: rank r owns Gi, Bi and the feature rows F of items [r*Ish, (r+1)*Ish) -- they never
+         cross xGMI; negatives are sampled rank-locally; a positive (u, i) is processed on owner(i).
+  users  range-partitioned: rank q owns rows [q*Ush, (q+1)*Ush) of Gu / Tu.  A step on rank r needs the rows of the
+         users in ITS batch, wherever they live:  all-to-all fetch (row b of the staging tables = user row of
+         triplet b) -> local step with BPRX_FLAG_EXPORT_USER_GRAD -> all-to-all return of the per-row gradients ->
+         owners add  -lr * grad  into their shard (bprx_scatter_add; duplicates, within and across ranks, sum up).
+  E, Bp  replicated; their dense gradient is all-reduced (sum) between bprx_step_begin and bprx_step_end, the only
+         all-reduce of the step.  The fetch overlaps the item projection (bprx_step_project) and the gradient return
+         overlaps nothing the next step needs before its own fetch.
+
+The global step is exactly the single-GPU batch-synchronous step on the concatenation of all ranks' batches
+(tests/test_gpu_dist.py checks that against the CPU oracle with two ranks).  sgd only in this mode.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_size(total, world):
+    return (total + world - 1) // world
+
+
+class UserRowExchange:
+    """Routing of user rows between the ranks that use them and the ranks that own them.  Pure tensor + collective
+    logic (no kernels): works on CPU tensors with gloo (tests) and on device tensors with nccl."""
+
+    def __init__(self, rank, world, users_total, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.ush = shard_size(users_total, world)
+        # gloo has no all_to_all for device tensors: stage through the host in that case (test mode only)
+        self.host_staged = dist.get_backend(group) != "nccl"
+
+    def _a2a(self, inp, in_splits, out_splits):
+        out = inp.new_empty((sum(out_splits),) + tuple(inp.shape[1:]))
+        if self.host_staged and inp.is_cuda:
+            o, i = out.cpu(), inp.cpu()
+            dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
+        return out
+
+    def plan(self, u_global):
+        """u_global: int tensor [B] of global user ids used by this rank's batch.
+        Returns (order, send_counts, recv_counts, recv_local_idx): `order` sorts the batch by owner rank;
+        recv_local_idx are the shard-local row ids the other ranks ask this rank for (in rank order)."""
+        owner = torch.div(u_global, self.ush, rounding_mode="floor").to(torch.int64)
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=self.world)
+        send = counts.cpu()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        send_counts, recv_counts = send.tolist(), recv.tolist()
+        local = (u_global[order] - owner[order] * self.ush).to(torch.int32)
+        recv_local_idx = self._a2a(local, send_counts, recv_counts)
+        return order, send_counts, recv_counts, recv_local_idx
+
+    def fetch(self, shard_tables, recv_local_idx, send_counts, recv_counts):
+        """Owners gather the requested rows of each shard table and send them back; returns the fetched rows in
+        batch-sorted order, one tensor per table."""
+        idx = recv_local_idx.long()
+        return [self._a2a(t.index_select(0, idx), recv_counts, send_counts) for t in shard_tables]
+
+    def give_back(self, grad_rows, send_counts, recv_counts):
+        """Send per-row gradients (batch-sorted order) to the owners; returns the rows each owner received, aligned
+        with the recv_local_idx of plan()."""
+        return [self._a2a(g, send_counts, recv_counts) for g in grad_rows]
+
+
+class ItemShardedVBPR:
+    """Per-rank driver of the item-sharded VBPR step (see module docstring)."""
+
+    def __init__(self, rank, world, users_total, Gu_shard, Tu_shard, Gi_shard, Bi_shard, F_shard, E, Bp, lr, reg,
+                 max_batch, feat_dtype="bf16", group=None, device=None):
+        from .engine import Engine, scatter_add
+        self._scatter_add = scatter_add
+        self.rank, self.world, self.group = rank, world, group
+        self.lr = lr
+        self.x = UserRowExchange(rank, world, users_total, group)
+        k, d = Gu_shard.shape[1], Tu_shard.shape[1]
+        self.eng = Engine(model="vbpr", num_users=max_batch, num_items=Gi_shard.shape[0], embed_k=k, embed_d=d,
+                          feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer="sgd", lr=lr, reg=reg,
+                          max_batch=max_batch, device=device, export_user_grad=True)
+        dev = self.eng.device
+        self.Gu_shard = Gu_shard.to(dev).contiguous()
+        self.Tu_shard = Tu_shard.to(dev).contiguous()
+        self.stage_Gu = torch.zeros((max_batch, k), dtype=torch.float32, device=dev)
+        self.stage_Tu = torch.zeros((max_batch, d), dtype=torch.float32, device=dev)
+        self.eng.bind(Gu=self.stage_Gu, Gi=Gi_shard, Bi=Bi_shard, Tu=self.stage_Tu, F=F_shard, E=E, Bp=Bp)
+        self.iota = torch.arange(max_batch, dtype=torch.int32, device=dev)
+        self.dense = self.eng.dense_grad()
+
+    def step(self, u_global, i_local, j_local, want_loss=False):
+        """One global batch-synchronous step; every rank calls it with its own local batch (int32 device tensors)."""
+        B = u_global.numel()
+        order, sc, rc, ridx = self.x.plan(u_global)
+        self.eng.step_project()                                   # P = F.[E|Bp]: independent of the user rows
+        gu, tu = self.x.fetch([self.Gu_shard, self.Tu_shard], ridx, sc, rc)
+        self.stage_Gu[:B].copy_(gu)
+        self.stage_Tu[:B].copy_(tu)
+        i_s, j_s = i_local[order].contiguous(), j_local[order].contiguous()
+        self.eng.step_begin(self.iota[:B], i_s, j_s)
+        if self.world > 1:
+            if self.x.host_staged:
+                h = self.dense.cpu()
+                dist.all_reduce(h, group=self.group)
+                self.dense.copy_(h)
+            else:
+                dist.all_reduce(self.dense, group=self.group)     # RCCL, 4*(D*d + D) bytes
+        loss = self.eng.step_end(want_loss=want_loss)
+        dG, dT = self.eng.user_grad()
+        g_back, t_back = self.x.give_back([dG[:B], dT[:B]], sc, rc)
+        self.eng.clear_user_grad(B)
+        self._scatter_add(self.Gu_shard, ridx, g_back.contiguous(), -self.lr)
+        self._scatter_add(self.Tu_shard, ridx, t_back.contiguous(), -self.lr)
+        return loss

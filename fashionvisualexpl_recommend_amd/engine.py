@@ -34,7 +34,7 @@ def as_index(x, device):
 class Engine:
     def __init__(self, model, num_users, num_items, embed_k, embed_d=0, feat_dim=0, feat_dtype="fp32",
                  optimizer="adam_tf23", lr=1e-3, reg=0.0, max_batch=256, device=None,
-                 beta1=0.9, beta2=0.999, epsilon=1e-7):
+                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False):
         if not torch.cuda.is_available():
             raise RuntimeError("fashionvisualexpl_recommend_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _ffi.lib()
@@ -46,7 +46,7 @@ class Engine:
         self.max_batch = int(max_batch)
         cfg = _ffi.Config(_ffi.ABI_VERSION, _ffi.MODEL[model], self.U, self.I, self.k, self.d, self.D,
                           _ffi.FEAT_DTYPE[feat_dtype], _ffi.OPTIMIZER[optimizer], self.device.index, self.max_batch,
-                          lr, reg, beta1, beta2, epsilon)
+                          lr, reg, beta1, beta2, epsilon, _ffi.FLAG_EXPORT_USER_GRAD if export_user_grad else 0)
         h = C.c_void_p()
         _ffi.check(None, self.lib.bprx_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -136,6 +136,22 @@ class Engine:
             self._dense_view = _DevView(p.value, n.value, self.device).tensor
         return self._dense_view
 
+    def step_project(self):
+        _ffi.check(self.h, self.lib.bprx_step_project(self.h, _stream()))
+
+    def user_grad(self):
+        """Zero-copy views [U,k], [U,d] of the staging tables that hold the exported user-row gradients."""
+        if getattr(self, "_ugrad", None) is None:
+            a, b = C.c_void_p(), C.c_void_p()
+            _ffi.check(self.h, self.lib.bprx_user_grad(self.h, C.byref(a), C.byref(b)))
+            g = _DevView(a.value, self.U * self.k, self.device).tensor.view(self.U, self.k)
+            t = _DevView(b.value, self.U * self.d, self.device).tensor.view(self.U, self.d) if self.d else None
+            self._ugrad = (g, t)
+        return self._ugrad
+
+    def clear_user_grad(self, n_rows):
+        _ffi.check(self.h, self.lib.bprx_clear_user_grad(self.h, int(n_rows), _stream()))
+
     def step_end(self, want_loss=True):
         _ffi.check(self.h, self.lib.bprx_step_end(self.h, _ptr(self._loss) if want_loss else None, _stream()))
         return self._loss
@@ -158,6 +174,16 @@ class Engine:
 
     def sync_check(self):
         _ffi.check(self.h, self.lib.bprx_sync_check(self.h, _stream()))
+
+
+def scatter_add(table, idx, rows, scale):
+    """table[idx] += scale * rows on the device (bprx_scatter_add); duplicates in idx are summed."""
+    lib = _ffi.lib()
+    assert table.is_contiguous() and rows.is_contiguous() and idx.dtype == torch.int32 and table.dtype == torch.float32
+    ncols = table.shape[1] if table.dim() == 2 else 1
+    rc = lib.bprx_scatter_add(_ptr(table), table.shape[0], ncols, _ptr(idx), _ptr(rows), idx.numel(), float(scale), _stream())
+    if rc < 0:
+        raise _ffi.BprxError(rc, "bprx_scatter_add failed")
 
 
 class _DevView:

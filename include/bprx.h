@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BPRX_ABI_VERSION 1
+#define BPRX_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define BPRX_API __attribute__((visibility("default")))
@@ -69,7 +69,14 @@ typedef struct {
   float lr;              /* --lr   train_rec.py:28 */
   float reg;             /* --reg  train_rec.py:44,69 */
   float beta1, beta2, epsilon; /* adam_tf23: 0.9, 0.999, 1e-7 (tf.optimizers.Adam defaults) */
+  int32_t flags;         /* BPRX_FLAG_* */
 } bprx_config;
+
+/* BPRX_FLAG_EXPORT_USER_GRAD (item-sharded multi-GPU, sgd only): the bound Gu/Tu are per-step STAGING rows fetched from
+   their owner ranks (row b = the user row of triplet b); the step leaves their summed gradients in the buffers of
+   bprx_user_grad() instead of applying them, and the caller routes those rows back to the owners
+   (bprx_scatter_add with scale = -lr) and clears them with bprx_clear_user_grad(). */
+enum { BPRX_FLAG_EXPORT_USER_GRAD = 1 };
 
 /* Device pointers to the model state.  Unused entries (BPRMF: Tu,F,E,Bp; sgd: every m_/v_) are NULL. */
 typedef struct {
@@ -112,6 +119,18 @@ BPRX_API int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t 
                     void *stream);
 BPRX_API int bprx_dense_grad(bprx_handle *h, float **ptr, int64_t *count);
 BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
+
+/* Item-sharded multi-GPU helpers.
+   bprx_step_project: the item-projection prologue of the step (P = F.[E|Bp]) on its own, so that it can overlap the
+   all-to-all that fetches the user rows; a following bprx_step_begin does not repeat it.
+   bprx_user_grad / bprx_clear_user_grad: see BPRX_FLAG_EXPORT_USER_GRAD.
+   bprx_scatter_add: table[idx[r], :] += scale * rows[r, :] for r < n (fp32 atomics; duplicates in idx are summed):
+   the owner-side application of routed gradient rows.  Stateless; all pointers are device pointers. */
+BPRX_API int bprx_step_project(bprx_handle *h, void *stream);
+BPRX_API int bprx_user_grad(bprx_handle *h, float **dGu, float **dTu);
+BPRX_API int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream);
+BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,
+                              int64_t n, float scale, void *stream);
 
 /* Model.predict_all() rows [u0,u1)   BPRMF.py:78-85 / VBPR.py:88-97.   out: fp32 [(u1-u0), I] */
 BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream);

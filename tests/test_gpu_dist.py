@@ -1,0 +1,79 @@
+"""Item-sharded VBPR with two ranks on ONE GPU (gloo for the collectives, HIP kernels for everything else): after a few
+global steps the union of the shards must equal the CPU oracle stepped on the concatenation of both ranks' batches."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fashionvisualexpl_recommend_amd import synth
+        from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR, shard_size
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        U, I, k, d, D, B, lr, reg = 45, 64, 8, 20, 256, 96, 0.05, 1e-3
+        ush, ish = shard_size(U, world), I // world
+        rs = np.random.RandomState(1)
+        F = synth.make_features(I, D, seed=1)
+        F = (F / np.abs(F).max()).astype(np.float32)
+        if dtype == "bf16":
+            F = orc.bf16_round(F)
+        t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k),
+                 Bi=(rs.standard_normal(I) * 0.01).astype(np.float32), Tu=synth.glorot_uniform(rs, U, d), F=F,
+                 E=synth.glorot_uniform(rs, D, d), Bp=synth.glorot_uniform(rs, D, 1).reshape(-1))
+        us, it = slice(rank * ush, min(U, (rank + 1) * ush)), slice(rank * ish, (rank + 1) * ish)
+        c = lambda a: torch.as_tensor(a.copy())
+        m = ItemShardedVBPR(rank, world, U, c(t["Gu"][us]), c(t["Tu"][us]), c(t["Gi"][it]), c(t["Bi"][it]), c(t["F"][it]),
+                            c(t["E"]), c(t["Bp"]), lr, reg, max_batch=B, feat_dtype=dtype, device=0)
+        o = orc.OracleModel(**t, quant=1 if dtype == "bf16" else 0)
+        for step in range(3):
+            batches = []
+            for r in range(world):                        # every rank knows every batch (test only) to feed the oracle
+                br = np.random.RandomState(100 + step * world + r)
+                nb = B - 10 * r                           # ragged
+                batches.append((br.randint(U, size=nb).astype(np.int32), br.randint(ish, size=nb).astype(np.int32),
+                                br.randint(ish, size=nb).astype(np.int32)))
+            u, i, j = batches[rank]
+            dev = lambda a: torch.as_tensor(a, device="cuda")
+            m.step(dev(u), dev(i), dev(j))
+            gu = np.concatenate([b[0] for b in batches])
+            gi = np.concatenate([b[1] + r * ish for r, b in enumerate(batches)])
+            gj = np.concatenate([b[2] + r * ish for r, b in enumerate(batches)])
+            o.step(gu, gi, gj, "sgd", lr, reg)
+        m.eng.sync_check()
+        rt, at = (2e-5, 2e-6) if dtype == "fp32" else (2e-3, 1e-4)
+        chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=rt, atol=at, err_msg=n)
+        chk(m.Gu_shard, o.Gu[us], "Gu shard")
+        chk(m.Tu_shard, o.Tu[us], "Tu shard")
+        chk(m.eng.t["Gi"], o.Gi[it], "Gi shard")
+        chk(m.eng.t["Bi"], o.Bi[it], "Bi shard")
+        chk(m.eng.t["E"], o.E, "E (replicated)")
+        chk(m.eng.t["Bp"], o.Bp, "Bp (replicated)")
+        # replicas of the shared parameters must agree BIT-exactly across ranks (same all-reduced gradient, same update)
+        e = [torch.zeros_like(m.eng.t["E"].cpu()) for _ in range(world)]
+        dist.all_gather(e, m.eng.t["E"].cpu())
+        assert all(torch.equal(e[0], x) for x in e)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_item_sharded_vbpr_two_ranks_match_oracle(dtype):
+    mp.spawn(_worker, args=(2, _free_port(), dtype), nprocs=2, join=True)

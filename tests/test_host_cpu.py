@@ -21,21 +21,21 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(REPO, "include", "bprx.h")).read()
     declared = sorted(set(re.findall(r"BPRX_API[^;(]*?\b(bprx_\w+)\s*\(", hdr)))
-    assert len(declared) >= 19
+    assert len(declared) >= 24
     assert sorted(_ffi.EXPORTS) == declared
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _ffi.lib().bprx_abi_version() == 1
+    assert _ffi.lib().bprx_abi_version() == _ffi.ABI_VERSION == 2
 
 
 def test_create_rejects_bad_config_without_gpu_work():
     L = _ffi.lib()
-    cfg = _ffi.Config(99, 0, 10, 10, 8, 0, 0, 0, 0, 0, 16, 0.1, 0.0, 0.9, 0.999, 1e-7)
+    cfg = _ffi.Config(99, 0, 10, 10, 8, 0, 0, 0, 0, 0, 16, 0.1, 0.0, 0.9, 0.999, 1e-7, 0)
     h = ctypes.c_void_p()
     assert L.bprx_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"abi_version" in L.bprx_last_error(None)
-    cfg.abi_version = 1
+    cfg.abi_version = _ffi.ABI_VERSION
     cfg.embed_k = 0
     assert L.bprx_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
 
