@@ -97,10 +97,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
+    # Rehearsal hook for a one-GPU box: BPRX_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (host-staged
+    # collectives) so that the N > 1 control flow can be exercised without N GPUs.  Never set by the driver.
+    rehearse = os.environ.get("BPRX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)      # "nccl" IS RCCL on ROCm
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" IS RCCL on ROCm
 
     w = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -115,7 +123,12 @@ def main():
     users_total = w["U"] * world
     if world > 1 and w["model"] == "vbpr":
         for n in ("E", "Bp"):
-            dist.broadcast(tables[n], src=0)
+            if rehearse:
+                hcopy = tables[n].cpu()
+                dist.broadcast(hcopy, src=0)
+                tables[n].copy_(hcopy)
+            else:
+                dist.broadcast(tables[n], src=0)
         if args.optimizer != "sgd":
             raise SystemExit("multi-GPU bench supports --optimizer sgd")
         from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
@@ -169,7 +182,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if rehearse else device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     eng.sync_check()
