@@ -133,14 +133,14 @@ def main():
             raise SystemExit("multi-GPU bench supports --optimizer sgd")
         from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
         sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
-                                  tables["F"], tables["E"], tables["Bp"], lr=0.05, reg=1e-4, max_batch=B,
+                                  tables["F"], tables["E"], tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B,
                                   feat_dtype=w["dtype"], device=local_rank)
         eng = sharded.eng
     else:
         if world > 1:
             raise SystemExit("multi-GPU bench is implemented for the VBPR workloads")
         eng = Engine(model=w["model"], num_users=w["U"], num_items=w["I"], embed_k=w["k"], embed_d=w["d"],
-                     feat_dim=w["D"], feat_dtype=w["dtype"], optimizer=args.optimizer, lr=0.05, reg=1e-4, max_batch=B,
+                     feat_dim=w["D"], feat_dtype=w["dtype"], optimizer=args.optimizer, lr=1e-4, reg=1e-4, max_batch=B,
                      device=local_rank).bind(**tables)
 
     gi = torch.Generator(device=device)
@@ -257,10 +257,10 @@ def cpu_baseline(w, tables, steps, optimizer):
     o = orc.OracleModel(**kw)
     rs = np.random.RandomState(5)
     cores = orc.lib().orc_num_threads()
-    o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 0.05, 1e-4)   # warm-up
+    o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 1e-4, 1e-4)   # warm-up
     t0 = time.perf_counter()
     for _ in range(steps):
-        o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 0.05, 1e-4)
+        o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 1e-4, 1e-4)
     dt = time.perf_counter() - t0
     return {"value": steps * B / dt, "unit": "triplets/s", "cores": cores, "kind": "port",
             "sample": "%d steps of B=%d triplets on a 1/%d slice (%d users x %d items) of the same tables, same k/d/D"

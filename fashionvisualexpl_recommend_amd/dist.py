@@ -50,9 +50,14 @@ class UserRowExchange:
         owner = torch.div(u_global, self.ush, rounding_mode="floor").to(torch.int64)
         order = torch.argsort(owner, stable=True)
         counts = torch.bincount(owner, minlength=self.world)
-        send = counts.cpu()
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
+        if self.host_staged or not counts.is_cuda:
+            send = counts.cpu()
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.group)
+        else:                                            # nccl moves device tensors only
+            recv_dev = torch.empty_like(counts)
+            dist.all_to_all_single(recv_dev, counts, group=self.group)
+            send, recv = counts.cpu(), recv_dev.cpu()
         send_counts, recv_counts = send.tolist(), recv.tolist()
         local = (u_global[order] - owner[order] * self.ush).to(torch.int32)
         recv_local_idx = self._a2a(local, send_counts, recv_counts)
