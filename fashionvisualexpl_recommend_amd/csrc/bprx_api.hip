@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->gbuf};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -72,6 +72,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   A(dalloc_zero(&h->lossb, MB));
   A(dalloc_zero(&h->loss_acc, (size_t)BPRX_DENSE_BLOCKS));
   A(dalloc_zero(&h->errflag, (size_t)1));
+  A(dalloc_zero(&h->gbuf, MB));
   if (vb) {
     h->PS = 16 * (int)((d + 1 + 15) / 16);
     const size_t PS = h->PS;
@@ -103,6 +104,22 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     free_scratch(h);
     delete h;
     return BPRX_E_NOMEM;
+  }
+  {
+    // item-side gradients through LDS bins (k_item_bin) when the whole item table fits a few rounds of workgroups;
+    // otherwise (very wide rows x very many items) the global-atomic staging path is kept.
+    const int PSv = vb ? h->PS : 4;
+    h->bin_rs = (int)k + PSv;
+    const int fixed = BPRX_BIN_QUEUE_BYTES + 64;
+    const int budget = 72 * 1024;                            // two workgroups per CU
+    int R = (budget - fixed) / (h->bin_rs * 4 + 8);
+    if (R > (int)I) R = (int)I;
+    h->bin_rows = R;
+    h->bin_count = R > 0 ? (int)((I + R - 1) / R) : 0;
+    h->bin_lds = R * (h->bin_rs * 4 + 8) + fixed;
+    h->item_mode = (R >= 8 && h->bin_count <= 4096) ? 1 : 0;
+    if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = atoi(e) && R >= 1;
+    if (h->item_mode && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // needs Wb
   }
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
@@ -210,6 +227,10 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   }
   h->proj_fresh = false;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
+  {
+    float lr_i = h->cfg.lr;                                                             // sgd: lr_t == lr
+    if ((rc = bprx_launch_item_bin(h, user, pos, neg, B, lr_i, s))) return rc;         // item rows + W, no atomics
+  }
   if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;                              // dE|dBp = F^T W
   // sparse tables are final now: apply their optimizer (does not depend on the dense all-reduce)
   float lr_t = h->cfg.lr;

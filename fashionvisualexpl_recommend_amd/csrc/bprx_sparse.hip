@@ -27,6 +27,8 @@ struct SparseArgs {
   int32_t *errflag;
   int U, I, k, d, PS;
   float reg;
+  int item_atomics;   // 1: item-side gradients by global atomics (staging tables); 0: left to k_item_bin
+  float *gout;        // [B] g_b = dloss/d(x+ - x-) for k_item_bin (item_atomics == 0)
 };
 
 template <int G>
@@ -153,10 +155,16 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   const float reg = a.reg, r2 = 2.f * reg;
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
-    atomicAdd(a.dBi + i, g + r2 * bi);
-    atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
-    a.flagU[u] = 1u; a.flagI[i] = 1u; a.flagI[j] = 1u;
+    a.flagU[u] = 1u;
+    if (a.item_atomics) {
+      atomicAdd(a.dBi + i, g + r2 * bi);
+      atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
+      a.flagI[i] = 1u; a.flagI[j] = 1u;
+    } else {
+      a.gout[b] = g;
+    }
   }
+  const bool ia = a.item_atomics != 0;
   // ---- backward: per-occurrence gradients from the same pre-update rows (L1/L2 hits) ----
   // Lane l of the group owns elements l, l+G, ...: every atomic wave-instruction then adds G CONTIGUOUS dwords per
   // row (full 64-B memory-side atomic requests).  The float4 layout of the forward pass would scatter each
@@ -165,8 +173,10 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   for (int c = lane; c < k; c += G) {
     float p = gu[c], q = gi[c], r = gj[c];
     atomicAdd(au + c, g * (q - r) + r2 * p);
-    atomicAdd(ai + c, g * p + r2 * q);
-    atomicAdd(aj + c, -g * p + r2 * r);
+    if (ia) {
+      atomicAdd(ai + c, g * p + r2 * q);
+      atomicAdd(aj + c, -g * p + r2 * r);
+    }
   }
   if (d) {
     float *at = a.dTu + (size_t)u * d;
@@ -175,8 +185,10 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       const bool last = c == d;
       float p = last ? 1.f : tu[c];
       if (!last) atomicAdd(at + c, g * (Pi[c] - Pj[c]) + r2 * p);
-      atomicAdd(wi + c, g * p);
-      atomicAdd(wj + c, -g * p);
+      if (ia) {
+        atomicAdd(wi + c, g * p);
+        atomicAdd(wj + c, -g * p);
+      }
     }
   }
 }
@@ -185,10 +197,11 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *Bi, float *Tu, SparseArgs a,
                                                    const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
-                                                   const int32_t *__restrict__ neg, int64_t B, float lr, int first_kind) {
+                                                   const int32_t *__restrict__ neg, int64_t B, float lr, int first_kind,
+                                                   int end_kind) {
   const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G + (int64_t)first_kind * B;
   const int lane = threadIdx.x % G;
-  if (job >= 3 * B) return;
+  if (job >= (int64_t)end_kind * B) return;
   const int kind = (int)(job / B);
   const int64_t b = job - (int64_t)kind * B;
   int row;
@@ -339,6 +352,132 @@ __global__ __launch_bounds__(256) void k_score_block(SparseArgs a, int u0, int u
   out[(size_t)(ub - u0) * a.I + i] = xv;
 }
 
+
+__device__ __forceinline__ uint16_t f2bf_s(float x) {   // round-to-nearest-even; inputs are finite
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Item-side gradients without global atomics.  Workgroup `bin` owns items [r0, r0+R): it scans the batch for
+// occurrences of its items (as positive or as negative), gathers the triplet's g_b and user rows, accumulates
+//   acc[row][0:k] += +-g*gamma_u        acc[row][k:k+d] += +-g*theta_u        acc[row][k+d] += +-g
+// in LDS (ds_add_f32), and then finishes each of its rows in one coalesced pass: the whole L2-regularised gradient is
+// applied to Gi/Bi in place (sgd) or stored to the staging tables (adam), and the W row for the backward projection is
+// written once (bf16 for the MFMA path) -- including the all-zero rows, so W needs no clearing pass.
+// The user side reads pre-update item rows in k_triplet_grad, which has completed before this kernel starts.
+// Global float atomics moved 1032 of the 1544 B per triplet at ~1 TB/s (the chip-wide atomic rate); here the same
+// bytes are plain gathers.  Matches are compacted in batch order (block scan), so the work list is deterministic.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BIN_TPT = 8;                     // triplets per thread and round
+constexpr int BIN_QCAP = 256 * BIN_TPT * 2;    // queue entries per round
+
+template <int G, bool ADAM>
+__global__ __launch_bounds__(256) void k_item_bin(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
+                                                  float *__restrict__ Wf, uint16_t *__restrict__ Wb,
+                                                  const float *__restrict__ gin, const int32_t *__restrict__ user,
+                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
+                                                  int64_t B, int R, int RS, float lr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float *acc = reinterpret_cast<float *>(lds_raw);                        // [R][RS]
+  int *cnt = reinterpret_cast<int *>(acc + (size_t)R * RS);               // [R][2]  occurrences as i / as j
+  uint32_t *queue = reinterpret_cast<uint32_t *>(cnt + 2 * R);            // [BIN_QCAP]
+  int *wsum = reinterpret_cast<int *>(queue + BIN_QCAP);                  // [8] cross-wave scan scratch
+  const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * R;
+  const int nrows = min(R, a.I - r0);
+  const int k = a.k, d = a.d;
+  for (int e = tid; e < R * RS; e += 256) acc[e] = 0.f;
+  for (int e = tid; e < 2 * R; e += 256) cnt[e] = 0;
+  __syncthreads();
+  const int NG = 256 / G, gid = tid / G, gl = tid % G;
+  for (int64_t b0 = 0; b0 < B; b0 += 256 * BIN_TPT) {
+    // ---- phase A: ordered compaction of this round's matches ----
+    int m = 0;                                         // pass 1: count (the flags are re-derived in pass 2:
+    const int64_t tb = b0 + (int64_t)tid * BIN_TPT;    // a register array indexed by a running count would spill)
+    unsigned flags = 0;
+#pragma unroll
+    for (int x = 0; x < BIN_TPT; ++x) {
+      const int64_t b = tb + x;
+      if (b < B) {
+        const unsigned pi = (unsigned)(pos[b] - r0), ni = (unsigned)(neg[b] - r0);
+        if (pi < (unsigned)nrows) { flags |= 1u << (2 * x); ++m; }
+        if (ni < (unsigned)nrows) { flags |= 2u << (2 * x); ++m; }
+      }
+    }
+    int incl = m;                                      // wave-inclusive scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane64 >= o) incl += v;
+    }
+    if (lane64 == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - m;
+    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+    for (int x = 0; x < BIN_TPT; ++x) {                // pass 2: ordered writes (batch order, positive before negative)
+      const uint32_t rel = (uint32_t)(tid * BIN_TPT + x) << 1;
+      if (flags & (1u << (2 * x))) queue[base++] = rel;
+      if (flags & (2u << (2 * x))) queue[base++] = rel | 1u;
+    }
+    __syncthreads();
+    // ---- phase B: one group of G lanes per match ----
+    for (int e = gid; e < total; e += NG) {
+      const uint32_t ent = queue[e];
+      const int64_t b = b0 + (ent >> 1);
+      const bool isneg = ent & 1u;
+      const int row = (isneg ? neg[b] : pos[b]) - r0;
+      const float gb = isneg ? -gin[b] : gin[b];
+      int u = user[b];
+      if ((unsigned)u >= (unsigned)a.U) u = 0;          // already reported by k_triplet_grad
+      const float *gu = a.Gu + (size_t)u * k;
+      float *ar = acc + (size_t)row * RS;
+      for (int c = gl; c < k; c += G) atomicAdd(ar + c, gb * gu[c]);
+      if (d) {
+        const float *tu = a.Tu + (size_t)u * d;
+        for (int c = gl; c < d; c += G) atomicAdd(ar + k + c, gb * tu[c]);
+      }
+      if (gl == 0) {
+        atomicAdd(ar + k + d, gb);
+        atomicAdd(cnt + 2 * row + (isneg ? 1 : 0), 1);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- phase C: finish the rows ----
+  const float reg = a.reg, r2 = 2.f * reg;
+  const int WC = RS - k;                                // W columns kept in LDS (PS for VBPR, 4 for BPRMF)
+  for (int e = tid; e < nrows * RS; e += 256) {
+    const int row = e / RS, c = e - row * RS;
+    const int item = r0 + row;
+    const int ni = cnt[2 * row], nj = cnt[2 * row + 1];
+    const float v = acc[e];
+    if (c < k) {
+      if (ni + nj) {
+        const size_t o = (size_t)item * k + c;
+        const float p = Gi[o];
+        const float grad = v + r2 * (float)(ni + nj) * p;
+        if (ADAM) a.dGi[o] = grad; else Gi[o] = p - lr * grad;
+      }
+    } else {
+      const int wc = c - k;
+      if (d) {
+        if (Wb) Wb[(size_t)item * a.PS + wc] = f2bf_s(wc <= d ? v : 0.f);
+        else Wf[(size_t)item * a.PS + wc] = wc <= d ? v : 0.f;
+      }
+      if (wc == d && (ni + nj)) {
+        const float p = Bi[item];
+        const float grad = v + r2 * (float)ni * p + (r2 * 0.1f) * (float)nj * p;
+        if (ADAM) a.dBi[item] = grad; else Bi[item] = p - lr * grad;
+      }
+      (void)WC;
+    }
+  }
+}
+
 SparseArgs make_args(bprx_handle *h, const float *P) {
   SparseArgs a;
   a.Gu = h->t.Gu; a.Gi = h->t.Gi; a.Bi = h->t.Bi; a.Tu = h->t.Tu;
@@ -347,6 +486,8 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.P = P; a.W = h->W; a.lossb = h->lossb; a.errflag = h->errflag;
   a.U = h->cfg.num_users; a.I = h->cfg.num_items; a.k = h->cfg.embed_k; a.d = h->cfg.embed_d; a.PS = h->PS;
   a.reg = h->cfg.reg;
+  a.item_atomics = h->item_mode ? 0 : 1;
+  a.gout = h->gbuf;
   return a;
 }
 
@@ -430,10 +571,43 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   const int G = pick_group(a.k, a.d, vec);
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
   // W must be all-zero here: k_cast_W (backward variants >= 8) re-zeroes it while converting; other variants don't
-  if (a.d && (h->bwd_variant < 8 || h->cfg.feat_dtype != BPRX_F_BF16))
+  if (a.d && !h->item_mode && (h->bwd_variant < 8 || h->cfg.feat_dtype != BPRX_F_BF16))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
+  return BPRX_OK;
+}
+
+int bprx_launch_item_bin(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t,
+                         hipStream_t s) {
+  if (!h->item_mode) return BPRX_OK;
+  SparseArgs a = make_args(h, nullptr);
+  const bool vec = vec_ok(h);
+  const int G = pick_group(a.k, a.d, vec);
+  const bool adam = h->cfg.optimizer == BPRX_OPT_ADAM_TF23;
+  const bool bf = h->cfg.feat_dtype == BPRX_F_BF16;
+  float *Wf = a.d && !bf ? h->W : nullptr;
+  uint16_t *Wb = a.d && bf ? (uint16_t *)h->Wb : nullptr;
+  BprxProfScope ps(h, BPRX_PHASE_ITEM_BIN, s);
+#define LAUNCH_BIN(GG, AD)                                                                                              \
+  do {                                                                                                                  \
+    auto kfn = k_item_bin<GG, AD>;                                                                                      \
+    if (h->bin_lds > 48 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, h->bin_lds);             \
+    hipLaunchKernelGGL(kfn, dim3(h->bin_count), dim3(256), h->bin_lds, s, a, h->t.Gi, h->t.Bi, Wf, Wb, h->gbuf, u, i, j, \
+                       B, h->bin_rows, h->bin_rs, lr_t);                                                                \
+  } while (0)
+#define LAUNCH_BIN_G(AD)                        \
+  switch (G) {                                  \
+    case 8: LAUNCH_BIN(8, AD); break;           \
+    case 16: LAUNCH_BIN(16, AD); break;         \
+    case 32: LAUNCH_BIN(32, AD); break;         \
+    default: LAUNCH_BIN(64, AD); break;         \
+  }
+  if (adam) { LAUNCH_BIN_G(true) } else { LAUNCH_BIN_G(false) }
+#undef LAUNCH_BIN_G
+#undef LAUNCH_BIN
+  BPRX_LAUNCH_CHECK(h, "k_item_bin");
   return BPRX_OK;
 }
 
@@ -445,8 +619,12 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     const bool vec = vec_ok(h);
     const int G = pick_group(a.k, a.d, vec);
     // first_kind = 1 skips the user rows (their gradients are exported to the caller: BPRX_FLAG_EXPORT_USER_GRAD)
+    // item rows are finished in place by k_item_bin when that mode is on: kinds [fk, ek)
     const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
-    DISPATCH_G(G, vec, k_apply_sgd, grid_for((3 - fk) * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B, lr_t, fk);
+    const int ek = h->item_mode ? 1 : 3;
+    if (ek > fk)
+      DISPATCH_G(G, vec, k_apply_sgd, grid_for((int64_t)(ek - fk) * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B,
+                 lr_t, fk, ek);
     BPRX_LAUNCH_CHECK(h, "k_apply_sgd");
     return BPRX_OK;
   }
