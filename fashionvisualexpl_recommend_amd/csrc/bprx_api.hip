@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->gbuf};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->bincnt, h->binptr, h->binrec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -72,7 +72,6 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   A(dalloc_zero(&h->lossb, MB));
   A(dalloc_zero(&h->loss_acc, (size_t)BPRX_DENSE_BLOCKS));
   A(dalloc_zero(&h->errflag, (size_t)1));
-  A(dalloc_zero(&h->gbuf, MB));
   if (vb) {
     h->PS = 16 * (int)((d + 1 + 15) / 16);
     const size_t PS = h->PS;
@@ -106,20 +105,31 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     return BPRX_E_NOMEM;
   }
   {
-    // item-side gradients through LDS bins (k_item_bin) when the whole item table fits a few rounds of workgroups;
+    // item-side gradients through LDS bins (k_item_bin) when the item table fits a few rounds of workgroups;
     // otherwise (very wide rows x very many items) the global-atomic staging path is kept.
     const int PSv = vb ? h->PS : 4;
     h->bin_rs = (int)k + PSv;
-    const int fixed = BPRX_BIN_QUEUE_BYTES + 64;
-    const int budget = 72 * 1024;                            // two workgroups per CU
-    int R = (budget - fixed) / (h->bin_rs * 4 + 8);
-    if (R > (int)I) R = (int)I;
-    h->bin_rows = R;
-    h->bin_count = R > 0 ? (int)((I + R - 1) / R) : 0;
-    h->bin_lds = R * (h->bin_rs * 4 + 8) + fixed;
-    h->item_mode = (R >= 8 && h->bin_count <= 4096) ? 1 : 0;
-    if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = atoi(e) && R >= 1;
+    const int row_bytes = h->bin_rs * 4 + 8;
+    int shift = 0;
+    while ((2 << shift) * row_bytes <= 38 * 1024 && (2 << shift) <= 1024) ++shift;    // R = 2^shift rows, <= 38 KB of LDS
+    h->bin_shift = shift;
+    const int R = 1 << shift;
+    h->bin_count = (int)((I + R - 1) / R);
+    h->bin_lds = R * row_bytes;
+    h->item_mode = (R * row_bytes <= 64 * 1024 && h->bin_count <= 8192) ? 1 : 0;
+    if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = atoi(e) ? (R * row_bytes <= 150 * 1024) : 0;
     if (h->item_mode && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // needs Wb
+    if (h->item_mode) {
+      bool ok2 = dalloc_zero(&h->bincnt, (size_t)h->bin_count) == hipSuccess &&
+                 dalloc_zero(&h->binptr, (size_t)h->bin_count + 1) == hipSuccess &&
+                 dalloc_zero((int4 **)&h->binrec, (size_t)2 * MB) == hipSuccess;
+      if (!ok2) {
+        snprintf(g_create_err, sizeof(g_create_err), "bin scratch allocation failed");
+        free_scratch(h);
+        delete h;
+        return BPRX_E_NOMEM;
+      }
+    }
   }
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
@@ -226,11 +236,9 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
   }
   h->proj_fresh = false;
+  if ((rc = bprx_launch_bin_index(h, pos, neg, B, s))) return rc;                       // bin lists of the 2B occurrences
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
-  {
-    float lr_i = h->cfg.lr;                                                             // sgd: lr_t == lr
-    if ((rc = bprx_launch_item_bin(h, user, pos, neg, B, lr_i, s))) return rc;         // item rows + W, no atomics
-  }
+  if ((rc = bprx_launch_item_bin(h, h->cfg.lr, s))) return rc;                          // item rows + W, no float atomics
   if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;                              // dE|dBp = F^T W
   // sparse tables are final now: apply their optimizer (does not depend on the dense all-reduce)
   float lr_t = h->cfg.lr;

@@ -10,7 +10,6 @@
 #include "bprx.h"
 
 #define BPRX_DENSE_BLOCKS 2048
-#define BPRX_BIN_QUEUE_BYTES (256 * 8 * 2 * 4)   // k_item_bin: 256 threads x BIN_TPT x 2 entries x 4 B
 
 struct bprx_handle {
   bprx_config cfg;
@@ -39,8 +38,9 @@ struct bprx_handle {
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
   int item_mode;                  // 1: item-side gradients by k_item_bin (LDS bins), 0: global atomics + apply
-  int bin_rows, bin_rs, bin_count, bin_lds;
-  float *gbuf;                    // [max_batch] g_b of the current step
+  int bin_shift, bin_rs, bin_count, bin_lds;   // bin = item >> bin_shift; LDS row stride (floats); #bins; LDS bytes
+  int32_t *bincnt, *binptr;       // [bin_count] counters / cursors, [bin_count + 1] list offsets
+  void *binrec;                   // [2 * max_batch] 16-byte records {user, +-g, item, role}
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
   // per-kernel HIP-event timing (bprx_profile_*)
@@ -91,8 +91,8 @@ int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_
                       int p_by_pair, float *x, hipStream_t s);
 int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
                              hipStream_t s);
-int bprx_launch_item_bin(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t,
-                         hipStream_t s);
+int bprx_launch_bin_index(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s);
+int bprx_launch_item_bin(bprx_handle *h, float lr_t, hipStream_t s);
 int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
                       float lr_t, hipStream_t s);
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s);

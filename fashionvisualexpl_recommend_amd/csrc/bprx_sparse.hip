@@ -28,7 +28,10 @@ struct SparseArgs {
   int U, I, k, d, PS;
   float reg;
   int item_atomics;   // 1: item-side gradients by global atomics (staging tables); 0: left to k_item_bin
-  float *gout;        // [B] g_b = dloss/d(x+ - x-) for k_item_bin (item_atomics == 0)
+  const int32_t *binptr;   // item bins (item_atomics == 0): list offsets, fill cursors, records
+  int32_t *bincur;
+  void *binrec;
+  int bin_shift;
 };
 
 template <int G>
@@ -160,8 +163,14 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       atomicAdd(a.dBi + i, g + r2 * bi);
       atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
       a.flagI[i] = 1u; a.flagI[j] = 1u;
-    } else {
-      a.gout[b] = g;
+    } else {                                           // one record per occurrence into its bin's list
+      struct Rec { int32_t u; float sg; int32_t item; int32_t pad; };
+      Rec *recs = reinterpret_cast<Rec *>(a.binrec);
+      const int bi_ = i >> a.bin_shift, bj_ = j >> a.bin_shift;
+      const int si = a.binptr[bi_] + atomicAdd(a.bincur + bi_, 1);
+      recs[si] = Rec{u, g, i, 0};
+      const int sj = a.binptr[bj_] + atomicAdd(a.bincur + bj_, 1);
+      recs[sj] = Rec{u, -g, j, 1};
     }
   }
   const bool ia = a.item_atomics != 0;
@@ -360,96 +369,102 @@ __device__ __forceinline__ uint16_t f2bf_s(float x) {   // round-to-nearest-even
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Item-side gradients without global atomics.  Workgroup `bin` owns items [r0, r0+R): it scans the batch for
-// occurrences of its items (as positive or as negative), gathers the triplet's g_b and user rows, accumulates
-//   acc[row][0:k] += +-g*gamma_u        acc[row][k:k+d] += +-g*theta_u        acc[row][k+d] += +-g
-// in LDS (ds_add_f32), and then finishes each of its rows in one coalesced pass: the whole L2-regularised gradient is
-// applied to Gi/Bi in place (sgd) or stored to the staging tables (adam), and the W row for the backward projection is
-// written once (bf16 for the MFMA path) -- including the all-zero rows, so W needs no clearing pass.
-// The user side reads pre-update item rows in k_triplet_grad, which has completed before this kernel starts.
+// Item-side gradients without global float atomics ("item bins").
+//   bin = item >> bin_shift: a workgroup of k_item_bin owns the R = 2^bin_shift items of one bin.
+//   k_bin_count    histogram of the batch's 2B item occurrences over the bins (LDS histogram per workgroup)
+//   k_bin_scan     exclusive scan -> binptr[nbins+1]; clears the counters / cursors for the fill
+//   k_triplet_grad appends, per occurrence, the record {user, +-g_b, item} to its bin's list (one int atomic on
+//                  the bin cursor per occurrence)
+//   k_item_bin     per bin: walks its record list (contiguous), gathers the user rows, accumulates
+//                     acc[row][0:k] += +-g*gamma_u    acc[row][k:k+d] += +-g*theta_u    acc[row][k+d] += +-g
+//                  in LDS (ds_add_f32), then finishes each of its rows in one coalesced pass: the L2-regularised
+//                  gradient is applied to Gi/Bi in place (sgd) or stored to the staging tables (adam), and the W row
+//                  of the backward projection is written once (bf16 for the MFMA path), all-zero rows included, so
+//                  W needs no clearing and no conversion pass.
+// The user side reads pre-update item rows in k_triplet_grad, which has completed before k_item_bin starts.
 // Global float atomics moved 1032 of the 1544 B per triplet at ~1 TB/s (the chip-wide atomic rate); here the same
-// bytes are plain gathers.  Matches are compacted in batch order (block scan), so the work list is deterministic.
+// bytes are plain row gathers.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int BIN_TPT = 8;                     // triplets per thread and round
-constexpr int BIN_QCAP = 256 * BIN_TPT * 2;    // queue entries per round
+struct BinRec { int32_t u; float sg; int32_t item; int32_t pad; };   // 16 B
+
+__global__ __launch_bounds__(256) void k_bin_count(const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
+                                                   int64_t B, int I, int shift, int nbins, int32_t *__restrict__ cnt) {
+  extern __shared__ int hist[];
+  for (int e = threadIdx.x; e < nbins; e += 256) hist[e] = 0;
+  __syncthreads();
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    int i = pos[b], j = neg[b];                        // same clamping as clamp_idx(): counts must match the appends
+    i = i < 0 ? 0 : (i >= I ? I - 1 : i);
+    j = j < 0 ? 0 : (j >= I ? I - 1 : j);
+    atomicAdd(&hist[i >> shift], 1);
+    atomicAdd(&hist[j >> shift], 1);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nbins; e += 256)
+    if (hist[e]) atomicAdd(cnt + e, hist[e]);
+}
+
+// one workgroup: binptr = exclusive scan of cnt; cnt (reused as the fill cursors) is cleared.
+__global__ __launch_bounds__(1024) void k_bin_scan(int32_t *__restrict__ cnt, int32_t *__restrict__ binptr, int nbins) {
+  __shared__ int part[1024];
+  const int per = (nbins + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(nbins, lo + per);
+  int s = 0;
+  for (int e = lo; e < hi; ++e) s += cnt[e];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int e = lo; e < hi; ++e) {
+    const int c = cnt[e];
+    binptr[e] = run;
+    run += c;
+    cnt[e] = 0;
+  }
+  if (threadIdx.x == 1023) binptr[nbins] = part[1023];
+}
 
 template <int G, bool ADAM>
 __global__ __launch_bounds__(256) void k_item_bin(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
                                                   float *__restrict__ Wf, uint16_t *__restrict__ Wb,
-                                                  const float *__restrict__ gin, const int32_t *__restrict__ user,
-                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
-                                                  int64_t B, int R, int RS, float lr) {
+                                                  const int32_t *__restrict__ binptr, const BinRec *__restrict__ recs,
+                                                  int shift, int RS, float lr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int R = 1 << shift;
   float *acc = reinterpret_cast<float *>(lds_raw);                        // [R][RS]
   int *cnt = reinterpret_cast<int *>(acc + (size_t)R * RS);               // [R][2]  occurrences as i / as j
-  uint32_t *queue = reinterpret_cast<uint32_t *>(cnt + 2 * R);            // [BIN_QCAP]
-  int *wsum = reinterpret_cast<int *>(queue + BIN_QCAP);                  // [8] cross-wave scan scratch
-  const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * R;
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x << shift;
   const int nrows = min(R, a.I - r0);
   const int k = a.k, d = a.d;
   for (int e = tid; e < R * RS; e += 256) acc[e] = 0.f;
   for (int e = tid; e < 2 * R; e += 256) cnt[e] = 0;
   __syncthreads();
   const int NG = 256 / G, gid = tid / G, gl = tid % G;
-  for (int64_t b0 = 0; b0 < B; b0 += 256 * BIN_TPT) {
-    // ---- phase A: ordered compaction of this round's matches ----
-    int m = 0;                                         // pass 1: count (the flags are re-derived in pass 2:
-    const int64_t tb = b0 + (int64_t)tid * BIN_TPT;    // a register array indexed by a running count would spill)
-    unsigned flags = 0;
-#pragma unroll
-    for (int x = 0; x < BIN_TPT; ++x) {
-      const int64_t b = tb + x;
-      if (b < B) {
-        const unsigned pi = (unsigned)(pos[b] - r0), ni = (unsigned)(neg[b] - r0);
-        if (pi < (unsigned)nrows) { flags |= 1u << (2 * x); ++m; }
-        if (ni < (unsigned)nrows) { flags |= 2u << (2 * x); ++m; }
-      }
+  const int e0 = binptr[blockIdx.x], e1 = binptr[blockIdx.x + 1];
+  for (int e = e0 + gid; e < e1; e += NG) {
+    const BinRec rec = recs[e];
+    const int row = rec.item - r0;
+    const float gb = rec.sg;
+    const float *gu = a.Gu + (size_t)rec.u * k;
+    float *ar = acc + (size_t)row * RS;
+    for (int c = gl; c < k; c += G) atomicAdd(ar + c, gb * gu[c]);
+    if (d) {
+      const float *tu = a.Tu + (size_t)rec.u * d;
+      for (int c = gl; c < d; c += G) atomicAdd(ar + k + c, gb * tu[c]);
     }
-    int incl = m;                                      // wave-inclusive scan
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane64 >= o) incl += v;
+    if (gl == 0) {
+      atomicAdd(ar + k + d, gb);
+      atomicAdd(cnt + 2 * row + (rec.pad ? 1 : 0), 1);
     }
-    if (lane64 == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - m;
-    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
-    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-#pragma unroll
-    for (int x = 0; x < BIN_TPT; ++x) {                // pass 2: ordered writes (batch order, positive before negative)
-      const uint32_t rel = (uint32_t)(tid * BIN_TPT + x) << 1;
-      if (flags & (1u << (2 * x))) queue[base++] = rel;
-      if (flags & (2u << (2 * x))) queue[base++] = rel | 1u;
-    }
-    __syncthreads();
-    // ---- phase B: one group of G lanes per match ----
-    for (int e = gid; e < total; e += NG) {
-      const uint32_t ent = queue[e];
-      const int64_t b = b0 + (ent >> 1);
-      const bool isneg = ent & 1u;
-      const int row = (isneg ? neg[b] : pos[b]) - r0;
-      const float gb = isneg ? -gin[b] : gin[b];
-      int u = user[b];
-      if ((unsigned)u >= (unsigned)a.U) u = 0;          // already reported by k_triplet_grad
-      const float *gu = a.Gu + (size_t)u * k;
-      float *ar = acc + (size_t)row * RS;
-      for (int c = gl; c < k; c += G) atomicAdd(ar + c, gb * gu[c]);
-      if (d) {
-        const float *tu = a.Tu + (size_t)u * d;
-        for (int c = gl; c < d; c += G) atomicAdd(ar + k + c, gb * tu[c]);
-      }
-      if (gl == 0) {
-        atomicAdd(ar + k + d, gb);
-        atomicAdd(cnt + 2 * row + (isneg ? 1 : 0), 1);
-      }
-    }
-    __syncthreads();
   }
-  // ---- phase C: finish the rows ----
+  __syncthreads();
   const float reg = a.reg, r2 = 2.f * reg;
-  const int WC = RS - k;                                // W columns kept in LDS (PS for VBPR, 4 for BPRMF)
   for (int e = tid; e < nrows * RS; e += 256) {
     const int row = e / RS, c = e - row * RS;
     const int item = r0 + row;
@@ -473,7 +488,6 @@ __global__ __launch_bounds__(256) void k_item_bin(SparseArgs a, float *__restric
         const float grad = v + r2 * (float)ni * p + (r2 * 0.1f) * (float)nj * p;
         if (ADAM) a.dBi[item] = grad; else Bi[item] = p - lr * grad;
       }
-      (void)WC;
     }
   }
 }
@@ -487,7 +501,7 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.U = h->cfg.num_users; a.I = h->cfg.num_items; a.k = h->cfg.embed_k; a.d = h->cfg.embed_d; a.PS = h->PS;
   a.reg = h->cfg.reg;
   a.item_atomics = h->item_mode ? 0 : 1;
-  a.gout = h->gbuf;
+  a.binptr = h->binptr; a.bincur = h->bincnt; a.binrec = h->binrec; a.bin_shift = h->bin_shift;
   return a;
 }
 
@@ -578,8 +592,21 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   return BPRX_OK;
 }
 
-int bprx_launch_item_bin(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t,
-                         hipStream_t s) {
+int bprx_launch_bin_index(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
+  if (!h->item_mode) return BPRX_OK;
+  BprxProfScope ps(h, BPRX_PHASE_BIN_INDEX, s);
+  int64_t blocks = (B + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  BPRX_HIP(h, hipMemsetAsync(h->bincnt, 0, (size_t)h->bin_count * sizeof(int32_t), s));   // cursors of the last step
+  hipLaunchKernelGGL(k_bin_count, dim3((unsigned)blocks), dim3(256), h->bin_count * sizeof(int), s, i, j, B, h->cfg.num_items,
+                     h->bin_shift, h->bin_count, h->bincnt);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, h->bincnt, h->binptr, h->bin_count);
+  BPRX_LAUNCH_CHECK(h, "k_bin_count/k_bin_scan");
+  return BPRX_OK;
+}
+
+int bprx_launch_item_bin(bprx_handle *h, float lr_t, hipStream_t s) {
   if (!h->item_mode) return BPRX_OK;
   SparseArgs a = make_args(h, nullptr);
   const bool vec = vec_ok(h);
@@ -594,8 +621,8 @@ int bprx_launch_item_bin(bprx_handle *h, const int32_t *u, const int32_t *i, con
     auto kfn = k_item_bin<GG, AD>;                                                                                      \
     if (h->bin_lds > 48 * 1024)                                                                                         \
       (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, h->bin_lds);             \
-    hipLaunchKernelGGL(kfn, dim3(h->bin_count), dim3(256), h->bin_lds, s, a, h->t.Gi, h->t.Bi, Wf, Wb, h->gbuf, u, i, j, \
-                       B, h->bin_rows, h->bin_rs, lr_t);                                                                \
+    hipLaunchKernelGGL(kfn, dim3(h->bin_count), dim3(256), h->bin_lds, s, a, h->t.Gi, h->t.Bi, Wf, Wb, h->binptr,       \
+                       (const BinRec *)h->binrec, h->bin_shift, h->bin_rs, lr_t);                                       \
   } while (0)
 #define LAUNCH_BIN_G(AD)                        \
   switch (G) {                                  \
