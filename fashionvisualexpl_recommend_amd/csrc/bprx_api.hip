@@ -116,7 +116,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     const int R = 1 << shift;
     h->bin_count = (int)((I + R - 1) / R);
     h->bin_lds = R * row_bytes;
-    h->item_mode = (R * row_bytes <= 64 * 1024 && h->bin_count <= 8192) ? 1 : 0;
+    // Measured on C2 (profiles/r01_sweeps.md): the bin path is CORRECT but slower than the atomic staging path it was
+    // meant to replace (bin_index 18 + appends +43 + k_item_bin 139 us vs 109 + 36 us): contended returning int atomics
+    // for the appends and latency-bound per-bin record walks.  It stays off unless BPRX_ITEM_MODE=1 (experiments).
+    h->item_mode = 0;
     if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = atoi(e) ? (R * row_bytes <= 150 * 1024) : 0;
     if (h->item_mode && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // needs Wb
     if (h->item_mode) {
