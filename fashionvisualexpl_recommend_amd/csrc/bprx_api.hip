@@ -134,6 +134,15 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       }
     }
   }
+  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    snprintf(g_create_err, sizeof(g_create_err), "side stream / event creation failed");
+    free_scratch(h);
+    delete h;
+    return BPRX_E_HIP;
+  }
+  if (const char *e = getenv("BPRX_NO_SIDE_STREAM")) { if (atoi(e)) { (void)hipStreamDestroy(h->side); h->side = nullptr; } }
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
   *out = h;
@@ -145,6 +154,9 @@ extern "C" int bprx_destroy(bprx_handle *h) {
   if (!h) return BPRX_OK;
   (void)hipSetDevice(h->cfg.device);
   free_scratch(h);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->prof_pending) { for (auto &r : *h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } delete h->prof_pending; }
   if (h->prof_free) { for (auto e : *h->prof_free) (void)hipEventDestroy(e); delete h->prof_free; }
   delete h;
@@ -242,15 +254,25 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if ((rc = bprx_launch_bin_index(h, pos, neg, B, s))) return rc;                       // bin lists of the 2B occurrences
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_item_bin(h, h->cfg.lr, s))) return rc;                          // item rows + W, no float atomics
-  if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;                              // dE|dBp = F^T W
-  // sparse tables are final now: apply their optimizer (does not depend on the dense all-reduce)
+  // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
+  // projection -- with VBPR it runs on the side stream beside it
   float lr_t = h->cfg.lr;
   if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
     h->adam_t += 1;
     float t = (float)h->adam_t;
     lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
   }
-  if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, s))) return rc;
+  if (vb && h->side) {
+    BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
+    BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, h->side))) return rc;
+    BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
+    h->side_pending = true;
+    if ((rc = bprx_launch_proj_bwd(h, s))) return rc;                                   // dE|dBp = F^T W
+  } else {
+    if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;
+    if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, s))) return rc;
+  }
   h->pending_B = B;
   return BPRX_OK;
 }
@@ -301,6 +323,10 @@ extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
   }
   int64_t B = h->pending_B;
   h->pending_B = 0;
+  if (h->side_pending) {                                  // join the side stream (sparse optimizer pass)
+    BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
+    h->side_pending = false;
+  }
   if (h->cfg.model == BPRX_MODEL_VBPR && (rc = bprx_launch_dense_update(h, lr_t, s))) return rc;
   if (loss_out && (rc = bprx_launch_loss_reduce(h, B, loss_out, s))) return rc;
   return BPRX_OK;

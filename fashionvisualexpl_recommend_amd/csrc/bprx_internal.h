@@ -43,6 +43,11 @@ struct bprx_handle {
   void *binrec;                   // [2 * max_batch] 16-byte records {user, +-g, item, role}
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
+  // side stream: the sparse optimizer pass (k_apply_sgd / adam sweeps: factor tables only) runs beside the backward
+  // projection (F, W, slabs only); forked after k_triplet_grad, joined in bprx_step_end
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
+  bool side_pending;
   // per-kernel HIP-event timing (bprx_profile_*)
   bool prof;
   struct ProfRec { int phase; hipEvent_t a, b; };
