@@ -142,7 +142,12 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     delete h;
     return BPRX_E_HIP;
   }
-  if (const char *e = getenv("BPRX_NO_SIDE_STREAM")) { if (atoi(e)) { (void)hipStreamDestroy(h->side); h->side = nullptr; } }
+  // Measured (C2): running the sparse optimizer pass beside the backward projection is SLOWER (0.385 vs 0.363 ms/step;
+  // both are bandwidth-bound and interfere: proj_bwd 93 -> 144 us, apply 35 -> 64 us).  Off unless BPRX_SIDE_STREAM=1.
+  {
+    const char *e = getenv("BPRX_SIDE_STREAM");
+    if (!(e && atoi(e))) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
+  }
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
   *out = h;
