@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->bincnt, h->binptr, h->binrec};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->bincnt, h->binptr, h->binrec, h->cntU, h->cntI};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -72,6 +72,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   A(dalloc_zero(&h->lossb, MB));
   A(dalloc_zero(&h->loss_acc, (size_t)BPRX_DENSE_BLOCKS));
   A(dalloc_zero(&h->errflag, (size_t)1));
+  A(dalloc_zero(&h->cntU, U));
+  A(dalloc_zero(&h->cntI, I));
   if (vb) {
     h->PS = 16 * (int)((d + 1 + 15) / 16);
     const size_t PS = h->PS;
@@ -134,6 +136,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       }
     }
   }
+  // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
+  h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;
+  if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
+  if (h->item_mode) h->fast_rows = 0;
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {

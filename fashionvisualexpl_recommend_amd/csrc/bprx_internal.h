@@ -37,6 +37,8 @@ struct bprx_handle {
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
+  int fast_rows;                  // sgd: rows used by exactly one triplet of the batch are updated in place
+  int32_t *cntU, *cntI;           // [U], [I] row multiplicities of the current batch (all-zero between steps)
   int item_mode;                  // 1: item-side gradients by k_item_bin (LDS bins), 0: global atomics + apply
   int bin_shift, bin_rs, bin_count, bin_lds;   // bin = item >> bin_shift; LDS row stride (floats); #bins; LDS bytes
   int32_t *bincnt, *binptr;       // [bin_count] counters / cursors, [bin_count + 1] list offsets

@@ -28,6 +28,12 @@ struct SparseArgs {
   int U, I, k, d, PS;
   float reg;
   int item_atomics;   // 1: item-side gradients by global atomics (staging tables); 0: left to k_item_bin
+  // exclusive-row fast path (sgd): multiplicity of every row in the batch; rows used by exactly one triplet are
+  // updated in place by that triplet's group (6 row transfers per triplet, no staging, no atomics, no apply pass)
+  int32_t *cntU, *cntI;
+  float *wGu, *wGi, *wBi, *wTu;   // writable aliases of the tables
+  int fast;
+  float lr;
   const int32_t *binptr;   // item bins (item_atomics == 0): list offsets, fill cursors, records
   int32_t *bincur;
   void *binrec;
@@ -94,7 +100,24 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v) {
   atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
 }
 
-// One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables.
+// Multiplicity of every user / item row in the batch (an item counts in both roles).  One thread per triplet, three
+// non-returning int atomics; the counters are reset to zero by k_apply_sgd.
+__global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
+                                                   const int32_t *__restrict__ neg, int64_t B, int U, int I,
+                                                   int32_t *__restrict__ cntU, int32_t *__restrict__ cntI) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int u = user[b], i = pos[b], j = neg[b];             // same clamping as clamp_idx()
+  u = u < 0 ? 0 : (u >= U ? U - 1 : u);
+  i = i < 0 ? 0 : (i >= I ? I - 1 : i);
+  j = j < 0 ? 0 : (j >= I ? I - 1 : j);
+  atomicAdd(cntU + u, 1);
+  atomicAdd(cntI + i, 1);
+  atomicAdd(cntI + j, 1);
+}
+
+// One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
+// (or, for rows no other triplet of the batch uses, the finished sgd update straight into the table).
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
                                                       const int32_t *__restrict__ pos,
@@ -155,14 +178,18 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   const float z = -cl;                                                 // softplus(z), stable form
   const float sp = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
   const float g = inr ? -1.0f / (1.0f + expf(diff)) : 0.f;            // -sigmoid(-diff)
-  const float reg = a.reg, r2 = 2.f * reg;
+  const float reg = a.reg, r2 = 2.f * reg, lr = a.lr;
+  // exclusive rows: nobody else reads or writes them in this batch, so the in-place update is batch-synchronous
+  const bool exU = a.fast && a.cntU[u] == 1;
+  const bool exI = a.fast && a.cntI[i] == 1, exJ = a.fast && a.cntI[j] == 1;      // i == j gives count 2: shared
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
-    a.flagU[u] = 1u;
+    if (!exU) a.flagU[u] = 1u;
     if (a.item_atomics) {
-      atomicAdd(a.dBi + i, g + r2 * bi);
-      atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
-      a.flagI[i] = 1u; a.flagI[j] = 1u;
+      if (exI) a.wBi[i] = bi - lr * (g + r2 * bi);
+      else { atomicAdd(a.dBi + i, g + r2 * bi); a.flagI[i] = 1u; }
+      if (exJ) a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj);
+      else { atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj); a.flagI[j] = 1u; }
     } else {                                           // one record per occurrence into its bin's list
       struct Rec { int32_t u; float sg; int32_t item; int32_t pad; };
       Rec *recs = reinterpret_cast<Rec *>(a.binrec);
@@ -179,24 +206,30 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   // row (full 64-B memory-side atomic requests).  The float4 layout of the forward pass would scatter each
   // instruction over every 4th dword and quadruple the request count (measured: 4x slower).
   float *au = a.dGu + (size_t)u * k, *ai = a.dGi + (size_t)i * k, *aj = a.dGi + (size_t)j * k;
+  float *pu = a.wGu + (size_t)u * k, *pi = a.wGi + (size_t)i * k, *pj = a.wGi + (size_t)j * k;
   for (int c = lane; c < k; c += G) {
-    float p = gu[c], q = gi[c], r = gj[c];
-    atomicAdd(au + c, g * (q - r) + r2 * p);
+    const float p = gu[c], q = gi[c], r = gj[c];
+    const float du = g * (q - r) + r2 * p;
+    if (exU) pu[c] = p - lr * du; else atomicAdd(au + c, du);
     if (ia) {
-      atomicAdd(ai + c, g * p + r2 * q);
-      atomicAdd(aj + c, -g * p + r2 * r);
+      const float di = g * p + r2 * q, dj = -g * p + r2 * r;
+      if (exI) pi[c] = q - lr * di; else atomicAdd(ai + c, di);
+      if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj);
     }
   }
   if (d) {
-    float *at = a.dTu + (size_t)u * d;
+    float *at = a.dTu + (size_t)u * d, *pt = a.wTu + (size_t)u * d;
     float *wi = a.W + (size_t)i * a.PS, *wj = a.W + (size_t)j * a.PS;
     for (int c = lane; c <= d; c += G) {                 // c == d: the Bp column of [theta_u | 1]
       const bool last = c == d;
-      float p = last ? 1.f : tu[c];
-      if (!last) atomicAdd(at + c, g * (Pi[c] - Pj[c]) + r2 * p);
-      if (ia) {
-        atomicAdd(wi + c, g * p);
-        atomicAdd(wj + c, -g * p);
+      const float p = last ? 1.f : tu[c];
+      if (!last) {
+        const float dt = g * (Pi[c] - Pj[c]) + r2 * p;
+        if (exU) pt[c] = p - lr * dt; else atomicAdd(at + c, dt);
+      }
+      if (ia) {                                          // W is all-zero before the step: a sole contributor stores
+        if (exI) wi[c] = g * p; else atomicAdd(wi + c, g * p);
+        if (exJ) wj[c] = -g * p; else atomicAdd(wj + c, -g * p);
       }
     }
   }
@@ -215,8 +248,14 @@ __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *
   const int64_t b = job - (int64_t)kind * B;
   int row;
   uint32_t *flag;
-  if (kind == 0) { row = clamp_idx(user[b], a.U, a.errflag, 1); flag = a.flagU + row; }
-  else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; }
+  int32_t *cntp;
+  if (kind == 0) { row = clamp_idx(user[b], a.U, a.errflag, 1); flag = a.flagU + row; cntp = a.cntU + row; }
+  else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; cntp = a.cntI + row; }
+  if (a.fast) {                                        // rows with multiplicity 1 were finished by k_triplet_grad
+    const int c1 = *cntp;
+    if (lane == 0 && c1) *cntp = 0;                    // reset for the next step (every job of the row may do it)
+    if (c1 == 1) return;
+  }
   unsigned claimed = 0;
   if (lane == 0) claimed = atomicExch(flag, 0u);
   claimed = __shfl(claimed, 0, G);
@@ -500,6 +539,10 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.P = P; a.W = h->W; a.lossb = h->lossb; a.errflag = h->errflag;
   a.U = h->cfg.num_users; a.I = h->cfg.num_items; a.k = h->cfg.embed_k; a.d = h->cfg.embed_d; a.PS = h->PS;
   a.reg = h->cfg.reg;
+  a.cntU = h->cntU; a.cntI = h->cntI;
+  a.wGu = h->t.Gu; a.wGi = h->t.Gi; a.wBi = h->t.Bi; a.wTu = h->t.Tu;
+  a.fast = h->fast_rows;
+  a.lr = h->cfg.lr;
   a.item_atomics = h->item_mode ? 0 : 1;
   a.binptr = h->binptr; a.bincur = h->bincnt; a.binrec = h->binrec; a.bin_shift = h->bin_shift;
   return a;
@@ -583,6 +626,10 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   SparseArgs a = make_args(h, h->P);
   const bool vec = vec_ok(h);
   const int G = pick_group(a.k, a.d, vec);
+  if (h->fast_rows) {
+    BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
+    hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI);
+  }
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
   // W must be all-zero here: k_cast_W (backward variants >= 8) re-zeroes it while converting; other variants don't
   if (a.d && !h->item_mode && (h->bwd_variant < 8 || h->cfg.feat_dtype != BPRX_F_BF16))

@@ -179,3 +179,31 @@ def test_philox_sampler_bit_exact_vs_cpu_twin():
     assert np.array_equal(u2, wu) and np.array_equal(i2, wi) and np.array_equal(j2, wj)
     for a, b, c in zip(u[:5000], i[:5000], j[:5000]):
         assert b in tr[a] and c not in tr[a]
+
+
+@pytest.mark.parametrize("model", ["bprmf", "vbpr"])
+def test_sgd_mostly_exclusive_rows_with_some_duplicates(model):
+    """Sparse batches (U, I >> B): most rows are used by exactly one triplet and take the in-place fast path, a few are
+    shared (duplicates, i == j, an item used as positive and as negative) and take the staging path.  Both must give
+    the batch-synchronous result of the oracle."""
+    U, I, k, B = 6000, 9000, 32, 512
+    d, D = (20, 128) if model == "vbpr" else (0, 0)
+    t = _tables(U, I, k, d, D, seed=11, bf16=(model == "vbpr"))
+    kw = dict(embed_d=d, feat_dim=D, feat_dtype="bf16") if model == "vbpr" else {}
+    e = _engine(model=model, num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=0.05, reg=1e-3, max_batch=B, **kw).bind(**t)
+    o = orc.OracleModel(**t, quant=1 if model == "vbpr" else 0)
+    for step in range(3):
+        u, i, j = _batch(U, I, B, 40 + step)
+        u[:6] = 17                                     # one user six times
+        i[10:13] = 4242                                # one item three times as positive
+        j[20] = i[21]                                  # an item as negative of one triplet and positive of another
+        j[30] = i[30]                                  # degenerate i == j
+        loss = e.step(_dev(u), _dev(i), _dev(j)).item()
+        want = o.step(u, i, j, "sgd", 0.05, 1e-3)
+        assert loss == pytest.approx(want, rel=1e-4 if d else 2e-5)
+        rt, at = (2e-5, 2e-6) if not d else (2e-3, 1e-4)
+        for n in (("Gu", "Gi", "Bi", "Tu", "E", "Bp") if d else ("Gu", "Gi", "Bi")):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step))
+    # the multiplicity counters must be back to zero for the next step
+    assert int(e.score_pairs(u, i).numel()) == B
+    e.sync_check()
