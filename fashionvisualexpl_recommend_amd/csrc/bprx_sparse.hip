@@ -207,19 +207,14 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   // instruction over every 4th dword and quadruple the request count (measured: 4x slower).
   float *au = a.dGu + (size_t)u * k, *ai = a.dGi + (size_t)i * k, *aj = a.dGi + (size_t)j * k;
   float *pu = a.wGu + (size_t)u * k, *pi = a.wGi + (size_t)i * k, *pj = a.wGi + (size_t)j * k;
-  // Exclusive rows of a one-chunk-per-lane layout are finished with 16-byte stores; everything read for the shared
-  // rows' atomics below is read BEFORE those stores issue (same wave, program order), i.e. pre-update.
-  const bool v4 = VEC && k <= G * 4 && (exU || (ia && (exI || exJ)));
-  float4 P4 = make_float4(0.f, 0.f, 0.f, 0.f), Q4 = P4, R4 = P4;
-  const int c4 = lane * 4;
-  if (v4 && c4 < k) { P4 = ld4(gu + c4); Q4 = ld4(gi + c4); R4 = ld4(gj + c4); }
-  const bool sU = !(v4 && exU), sI = ia && !(v4 && exI), sJ = ia && !(v4 && exJ);   // rows still on the scalar path
-  if (sU || sI || sJ) {
-    for (int c = lane; c < k; c += G) {
-      const float p = gu[c], q = gi[c], r = gj[c];
-      if (sU) { const float du = g * (q - r) + r2 * p; if (exU) pu[c] = p - lr * du; else atomicAdd(au + c, du); }
-      if (sI) { const float di = g * p + r2 * q; if (exI) pi[c] = q - lr * di; else atomicAdd(ai + c, di); }
-      if (sJ) { const float dj = -g * p + r2 * r; if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj); }
+  for (int c = lane; c < k; c += G) {
+    const float p = gu[c], q = gi[c], r = gj[c];
+    const float du = g * (q - r) + r2 * p;
+    if (exU) pu[c] = p - lr * du; else atomicAdd(au + c, du);
+    if (ia) {
+      const float di = g * p + r2 * q, dj = -g * p + r2 * r;
+      if (exI) pi[c] = q - lr * di; else atomicAdd(ai + c, di);
+      if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj);
     }
   }
   if (d) {
@@ -238,51 +233,6 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       }
     }
   }
-  if (v4 && c4 < k) {
-    if (exU) {
-      const float4 o = make_float4(P4.x - lr * (g * (Q4.x - R4.x) + r2 * P4.x), P4.y - lr * (g * (Q4.y - R4.y) + r2 * P4.y),
-                                   P4.z - lr * (g * (Q4.z - R4.z) + r2 * P4.z), P4.w - lr * (g * (Q4.w - R4.w) + r2 * P4.w));
-      *reinterpret_cast<float4 *>(pu + c4) = o;
-    }
-    if (ia && exI) {
-      const float4 o = make_float4(Q4.x - lr * (g * P4.x + r2 * Q4.x), Q4.y - lr * (g * P4.y + r2 * Q4.y),
-                                   Q4.z - lr * (g * P4.z + r2 * Q4.z), Q4.w - lr * (g * P4.w + r2 * Q4.w));
-      *reinterpret_cast<float4 *>(pi + c4) = o;
-    }
-    if (ia && exJ) {
-      const float4 o = make_float4(R4.x - lr * (-g * P4.x + r2 * R4.x), R4.y - lr * (-g * P4.y + r2 * R4.y),
-                                   R4.z - lr * (-g * P4.z + r2 * R4.z), R4.w - lr * (-g * P4.w + r2 * R4.w));
-      *reinterpret_cast<float4 *>(pj + c4) = o;
-    }
-  }
-}
-
-// sgd, sparse regime (4B <= min(U, I): almost every row is exclusive and already finished): ONE THREAD per occurrence
-// checks the multiplicity; the few shared rows are applied by the thread that claims them.
-__global__ __launch_bounds__(256) void k_apply_sgd_sparse(float *Gu, float *Gi, float *Bi, float *Tu, SparseArgs a,
-                                                          const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
-                                                          const int32_t *__restrict__ neg, int64_t B, float lr) {
-  const int64_t job = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (job >= 3 * B) return;
-  const int kind = (int)(job / B);
-  const int64_t b = job - (int64_t)kind * B;
-  int row;
-  uint32_t *flag;
-  int32_t *cntp;
-  if (kind == 0) { row = clamp_idx(user[b], a.U, a.errflag, 1); flag = a.flagU + row; cntp = a.cntU + row; }
-  else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; cntp = a.cntI + row; }
-  const int c1 = *cntp;
-  if (c1) *cntp = 0;
-  if (c1 == 1) return;
-  if (atomicExch(flag, 0u) == 0u) return;
-  const int k = a.k, d = a.d;
-  float *p = (kind == 0 ? Gu : Gi) + (size_t)row * k, *gr = (kind == 0 ? a.dGu : a.dGi) + (size_t)row * k;
-  for (int c = 0; c < k; ++c) { p[c] -= lr * gr[c]; gr[c] = 0.f; }
-  if (kind == 0 && d) {
-    float *t = Tu + (size_t)row * d, *gt = a.dTu + (size_t)row * d;
-    for (int c = 0; c < d; ++c) { t[c] -= lr * gt[c]; gt[c] = 0.f; }
-  }
-  if (kind != 0) { Bi[row] -= lr * a.dBi[row]; a.dBi[row] = 0.f; }
 }
 
 // sgd: one group per occurrence; the first to claim a touched row applies  p -= lr*dG  and re-zeroes dG.
@@ -746,12 +696,6 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     // item rows are finished in place by k_item_bin when that mode is on: kinds [fk, ek)
     const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
     const int ek = h->item_mode ? 1 : 3;
-    if (h->fast_rows && fk == 0 && ek == 3 && 4 * B <= (int64_t)(U < I ? U : I)) {
-      hipLaunchKernelGGL(k_apply_sgd_sparse, dim3((unsigned)((3 * B + 255) / 256)), dim3(256), 0, s, h->t.Gu, h->t.Gi, h->t.Bi,
-                         h->t.Tu, a, u, i, j, B, lr_t);
-      BPRX_LAUNCH_CHECK(h, "k_apply_sgd_sparse");
-      return BPRX_OK;
-    }
     if (ek > fk)
       DISPATCH_G(G, vec, k_apply_sgd, grid_for((int64_t)(ek - fk) * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B,
                  lr_t, fk, ek);
