@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libbprx.so")
-SOURCES = ["bprx_api.hip", "bprx_sparse.hip", "bprx_proj.hip", "bprx_philox.hip", "bprx_sampler.cpp"]
+SOURCES = ["bprx_api.hip", "bprx_sparse.hip", "bprx_proj.hip", "bprx_philox.hip", "bprx_eval.hip", "bprx_sampler.cpp"]
 
 
 def _hipcc():

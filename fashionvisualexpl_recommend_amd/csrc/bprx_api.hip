@@ -363,6 +363,8 @@ extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *o
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;
   }
+  if (h->cfg.embed_k % 2 == 0 && h->cfg.embed_d % 2 == 0 && !getenv("BPRX_NAIVE_SCORE_BLOCK"))
+    return bprx_launch_score_gemm(h, u0, u1, out, s);          // fp32 MFMA GEMM (K step 2)
   return bprx_launch_score_block(h, u0, u1, out, s);
 }
 

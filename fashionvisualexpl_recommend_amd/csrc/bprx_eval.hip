@@ -1,0 +1,183 @@
+// bprx_eval.hip -- device-side evaluation.
+//   k_score_gemm   predict_all rows [u0,u1): out[u][i] = Bi[i] + <Gu[u],Gi[i]> (+ <Tu[u],P_i[0:d]> + P_i[d])
+//                  (BPRMF.py:78-85 / VBPR.py:88-97) as an fp32-in / fp32-accumulate MFMA GEMM
+//                  (v_mfma_f32_32x32x2_f32: exact fp32 products, k-ordered fp32 sums -- no bf16 in the ranking path)
+//   k_eval_users   Evaluator._eval_by_user (Evaluator.py:82-128) from a block of score rows: exact integer rank
+//                  counting, so for identical fp32 scores the metrics equal the reference's definitions bit for bit
+//                  (ties included: negatives rank before the held-out items, `>=` counts against them).
+// The U x I matrix is never resident: the caller walks user blocks (scores of one block: nb x I fp32 in HBM).
+#include "bprx_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TM = 128, TN = 128, GKC = 16, GLD = GKC + 1;   // 17-float LDS rows: conflict-free column reads
+
+struct GemmArgs {
+  const float *Gu, *Gi, *Bi, *Tu, *P;
+  int U, I, k, d, PS;
+};
+
+// one K phase: acc += A[rows, 0:K] . B[cols, 0:K]^T   (A row stride lda, B row stride ldb)
+__device__ __forceinline__ void gemm_phase(const float *__restrict__ A, int lda, int arow0, int arows,
+                                           const float *__restrict__ Bm, int ldb, int brow0, int brows, int K,
+                                           float (*As)[GLD], float (*Bs)[GLD], f32x16 (&acc)[2][2], int wr, int wc, int lane) {
+  const int t = threadIdx.x;
+  for (int k0 = 0; k0 < K; k0 += GKC) {
+    __syncthreads();
+    // 128 rows x 16 floats per operand: thread t -> row t/2, 8 floats at (t%2)*8
+    {
+      const int r = t >> 1, c0 = (t & 1) * 8;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int kk = k0 + c0 + x;
+        As[r][c0 + x] = (r < arows && kk < K) ? A[(size_t)(arow0 + r) * lda + kk] : 0.f;
+        Bs[r][c0 + x] = (r < brows && kk < K) ? Bm[(size_t)(brow0 + r) * ldb + kk] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GKC; kk += 2) {
+      const int kq = kk + (lane >> 5), rr = lane & 31;
+      const float a0 = As[wr * 64 + rr][kq], a1 = As[wr * 64 + 32 + rr][kq];
+      const float b0 = Bs[wc * 64 + rr][kq], b1 = Bs[wc * 64 + 32 + rr][kq];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_score_gemm(GemmArgs g, int u0, int u1, float *__restrict__ out) {
+  __shared__ float As[TM][GLD];
+  __shared__ float Bs[TN][GLD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  const int i0 = blockIdx.x * TN, ub = u0 + blockIdx.y * TM;
+  const int arows = min(TM, u1 - ub), brows = min(TN, g.I - i0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  gemm_phase(g.Gu, g.k, ub, arows, g.Gi, g.k, i0, brows, g.k, As, Bs, acc, wr, wc, lane);
+  if (g.d) gemm_phase(g.Tu, g.d, ub, arows, g.P, g.PS, i0, brows, g.d, As, Bs, acc, wr, wc, lane);
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int ic = i0 + wc * 64 + b * 32 + (lane & 31);
+    if (ic >= g.I) continue;
+    const float bias = g.Bi[ic] + (g.d ? g.P[(size_t)ic * g.PS + g.d] : 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ur = ub + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ur < u1) out[(size_t)(ur - u0) * g.I + ic] = acc[a][b][r] + bias;   // same order as BPRMF.py:85: Bi + (...)
+      }
+  }
+}
+
+constexpr int EVMAX = 32;   // held-out items per user handled on the device (the reference's split holds out 1)
+
+// One workgroup per user.  out[5] = hr, prec, rec, auc, ndcg (double); out[0] = -1 marks "no held-out items"
+// (Evaluator.py:88-89: such users are skipped), out[0] = -2 marks "too many held-out items for the device path".
+__global__ __launch_bounds__(256) void k_eval_users(const float *__restrict__ S, int u0, int I,
+                                                    const int64_t *__restrict__ tr_ptr, const int32_t *__restrict__ tr_items,
+                                                    const int64_t *__restrict__ ev_ptr, const int32_t *__restrict__ ev_items,
+                                                    int K, double *__restrict__ out) {
+  __shared__ float sp[EVMAX];
+  __shared__ int ev[EVMAX];
+  __shared__ int cnt_all[EVMAX], cnt_sub[EVMAX];
+  __shared__ int n_tr_only;
+  const int u = u0 + blockIdx.x, tid = threadIdx.x;
+  const float *s = S + (size_t)blockIdx.x * I;
+  double *o = out + (size_t)blockIdx.x * 5;
+  const int64_t e0 = ev_ptr[u];
+  const int nev = (int)(ev_ptr[u + 1] - e0);
+  if (nev <= 0 || nev > EVMAX) {
+    if (tid < 5) o[tid] = tid == 0 ? (nev <= 0 ? -1.0 : -2.0) : 0.0;
+    return;
+  }
+  if (tid < nev) {
+    const int it = ev_items[e0 + tid];
+    ev[tid] = it;
+    sp[tid] = s[it];
+    cnt_all[tid] = 0;
+    cnt_sub[tid] = 0;
+  }
+  if (tid == 0) n_tr_only = 0;
+  __syncthreads();
+  // #(all items with score >= sp_t): one sweep of the score row per held-out item (the row is L2-resident)
+  for (int t = 0; t < nev; ++t) {
+    const float spt = sp[t];
+    int loc = 0;
+    for (int i = tid; i < I; i += 256) loc += s[i] >= spt ? 1 : 0;
+    if (loc) atomicAdd(&cnt_all[t], loc);
+  }
+  // minus the train items that are not held-out items, minus the held-out items themselves
+  const int64_t t0 = tr_ptr[u];
+  const int ntr = (int)(tr_ptr[u + 1] - t0);
+  for (int q = tid; q < ntr; q += 256) {
+    const int it = tr_items[t0 + q];
+    bool is_ev = false;
+    for (int t = 0; t < nev; ++t) is_ev |= ev[t] == it;
+    if (is_ev || (unsigned)it >= (unsigned)I) continue;
+    atomicAdd(&n_tr_only, 1);
+    const float v = s[it];
+    for (int t = 0; t < nev; ++t)
+      if (v >= sp[t]) atomicAdd(&cnt_sub[t], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long long position = 0;
+    int hits = 0;
+    const long long nneg = (long long)I - n_tr_only - nev;
+    const long long topn = (long long)K < nneg + nev ? (long long)K : nneg + nev;
+    for (int t = 0; t < nev; ++t) {
+      int ge_ev = 0, before = 0;                         // held-out items with score >= sp_t; those ranked before t
+      for (int q = 0; q < nev; ++q) {
+        if (sp[q] >= sp[t]) ++ge_ev;
+        if (q != t && (sp[q] > sp[t] || (sp[q] == sp[t] && q < t))) ++before;
+      }
+      const long long neg_ge = (long long)cnt_all[t] - cnt_sub[t] - ge_ev;   // Evaluator.py:96-98
+      position += neg_ge;
+      if (neg_ge + before < topn) ++hits;                                    // heapq.nlargest membership, :104-115
+    }
+    o[0] = hits > 0 ? 1.0 : 0.0;                                             // :117
+    o[1] = topn > 0 ? (double)hits / (double)topn : 0.0;                     // :123
+    o[2] = (double)hits / (double)nev;                                       // :126
+    o[3] = 1.0 - (double)position / ((double)nneg * (double)nev);            // :100
+    o[4] = position < K ? log(2.0) / log((double)position + 2.0) : 0.0;      // :120
+  }
+}
+
+}  // namespace
+
+// used by bprx_score_block when the factor widths allow the MFMA path (K step of 2)
+int bprx_launch_score_gemm(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s) {
+  GemmArgs g;
+  g.Gu = h->t.Gu; g.Gi = h->t.Gi; g.Bi = h->t.Bi; g.Tu = h->t.Tu; g.P = h->P;
+  g.U = h->cfg.num_users; g.I = h->cfg.num_items; g.k = h->cfg.embed_k; g.d = h->cfg.embed_d; g.PS = h->PS;
+  dim3 grid((g.I + TN - 1) / TN, (u1 - u0 + TM - 1) / TM);
+  hipLaunchKernelGGL(k_score_gemm, grid, dim3(256), 0, s, g, u0, u1, out);
+  BPRX_LAUNCH_CHECK(h, "k_score_gemm");
+  return BPRX_OK;
+}
+
+extern "C" int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, const int64_t *train_ptr,
+                               const int32_t *train_items, const int64_t *eval_ptr, const int32_t *eval_items, int32_t K,
+                               double *out, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (u0 < 0 || u1 > h->cfg.num_users || u0 > u1 || !scores || !train_ptr || !train_items || !eval_ptr || !eval_items ||
+      !out || K <= 0)
+    BPRX_FAIL(h, BPRX_E_INVALID, "eval_users: bad argument");
+  if (u0 == u1) return BPRX_OK;
+  hipLaunchKernelGGL(k_eval_users, dim3(u1 - u0), dim3(256), 0, (hipStream_t)stream, scores, u0, h->cfg.num_items, train_ptr,
+                     train_items, eval_ptr, eval_items, K, out);
+  BPRX_LAUNCH_CHECK(h, "k_eval_users");
+  return BPRX_OK;
+}

@@ -105,6 +105,7 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s);
 int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStream_t s);
 int bprx_launch_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);
+int bprx_launch_score_gemm(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);
 // projection part (bprx_proj.hip)
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s);
 int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s);

@@ -162,6 +162,13 @@ class Engine:
         _ffi.check(self.h, self.lib.bprx_score_block(self.h, u0, u1, _ptr(out), _stream()))
         return out
 
+    def eval_users(self, u0, u1, scores, train_csr, eval_csr, K):
+        """bprx_eval_users: per-user (hr, prec, rec, auc, ndcg) as a float64 device tensor [(u1-u0), 5]."""
+        out = torch.empty((u1 - u0, 5), dtype=torch.float64, device=self.device)
+        _ffi.check(self.h, self.lib.bprx_eval_users(self.h, u0, u1, _ptr(scores), _ptr(train_csr[0]), _ptr(train_csr[1]),
+                                                    _ptr(eval_csr[0]), _ptr(eval_csr[1]), int(K), _ptr(out), _stream()))
+        return out
+
     def profile(self, on):
         _ffi.check(self.h, self.lib.bprx_profile_enable(self.h, 1 if on else 0))
 

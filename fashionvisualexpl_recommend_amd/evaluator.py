@@ -78,8 +78,53 @@ class Evaluator:
             u1 = min(U, u0 + self.user_block)
             yield u0, self.model.predict_block(u0, u1)
 
+    # ---- device path (libbprx bprx_score_block + bprx_eval_users): used whenever the model runs on the engine ----
+    def _device_csr(self, lists, device):
+        import torch
+        indptr = np.zeros(len(lists) + 1, dtype=np.int64)
+        for u, l in enumerate(lists):
+            indptr[u + 1] = indptr[u] + len(l)
+        items = np.fromiter((i for l in lists for i in l), dtype=np.int32, count=int(indptr[-1]))
+        if items.size == 0:
+            items = np.zeros(1, np.int32)
+        return torch.as_tensor(indptr, device=device), torch.as_tensor(items, device=device)
+
+    def _metrics_device(self):
+        import torch
+        eng = self.model.engine
+        if getattr(self, "_csr", None) is None:
+            U = self.model.data.num_users
+            pad = lambda l: list(l[:U]) + [[] for _ in range(U - len(l))]
+            self._csr = {"train": self._device_csr(pad(self.data.training_list), eng.device),
+                         "test": self._device_csr(pad(self.data.test_list), eng.device),
+                         "val": self._device_csr(pad(self.data.validation_list), eng.device)
+                         if self.data.validation_list else None}
+        U = self.model.data.num_users
+        rows = {"test": [], "val": []}
+        for u0 in range(0, U, self.user_block):
+            u1 = min(U, u0 + self.user_block)
+            sc = eng.score_block(u0, u1)
+            for key in ("test", "val"):
+                if self._csr[key] is not None:
+                    rows[key].append(eng.eval_users(u0, u1, sc, self._csr["train"], self._csr[key], self.k))
+        out = {}
+        for key, suf in (("test", "_t"), ("val", "_v")):
+            if not rows[key]:
+                continue
+            r = torch.cat(rows[key]).cpu().numpy()
+            if (r[:, 0] == -2).any():
+                return None                                # > 32 held-out items for some user: host path
+            r = r[r[:, 0] >= 0]
+            hr, p, rr, auc, ndcg = r.mean(axis=0).tolist()
+            out.update({"hr" + suf: hr, "p" + suf: p, "r" + suf: rr, "auc" + suf: auc, "ndcg" + suf: ndcg})
+        return out
+
     def metrics(self):
         """The ten means of Evaluator.py:189-193 with the TRUE auc_t (eval() applies the reference's aliasing)."""
+        if getattr(self.model, "engine", None) is not None and not getattr(self, "force_host", False):
+            m = self._metrics_device()
+            if m is not None:
+                return m
         res_t, res_v = [], []
         val = bool(self.data.validation_list)
         for u0, sc in self._score_blocks():

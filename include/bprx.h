@@ -147,6 +147,16 @@ enum {
 BPRX_API int bprx_profile_enable(bprx_handle *h, int on);
 BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);
 
+/* Evaluator._eval_by_user on the device (Evaluator.py:82-128) for users [u0,u1) from their score rows
+   (`scores` = the output of bprx_score_block for the same range).  CSR lists are DEVICE pointers: indptr int64 [U+1]
+   indexed by the global user id, items int32.  out: double [(u1-u0), 5] = hr, prec, rec, auc, ndcg per user;
+   out[.][0] == -1: the user has no held-out item (skipped by the reference, :88-89); == -2: more than 32 held-out
+   items (use the host evaluator).  Exact integer rank counting: for identical fp32 scores the values equal the
+   reference's, ties included. */
+BPRX_API int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, const int64_t *train_ptr,
+                             const int32_t *train_items, const int64_t *eval_ptr, const int32_t *eval_items, int32_t K,
+                             double *out, void *stream);
+
 /* Synchronise `stream` and report deferred device-side errors (index out of range). */
 BPRX_API int bprx_sync_check(bprx_handle *h, void *stream);
 

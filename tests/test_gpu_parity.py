@@ -207,3 +207,49 @@ def test_sgd_mostly_exclusive_rows_with_some_duplicates(model):
     # the multiplicity counters must be back to zero for the next step
     assert int(e.score_pairs(u, i).numel()) == B
     e.sync_check()
+
+
+def test_device_eval_matches_reference_golden(golden_dir):
+    """bprx_eval_users fed with the SAME score matrices the reference's own Evaluator was run on
+    (tests/golden/gen_golden.py): per-user metrics averaged exactly like Evaluator.py:189-193, ties included."""
+    import json
+    import os
+    g = json.load(open(os.path.join(golden_dir, "golden.json")))
+    ds = json.load(open(os.path.join(golden_dir, "dataset_tiny.json")))
+    cases = [("eval_tiny", np.load(os.path.join(golden_dir, "eval_tiny_scores.npy")),
+              ds["loaded_train"], ds["loaded_val"], ds["loaded_test"])]
+    tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
+    cases.append(("eval_c1", np.random.RandomState(g["eval_c1"]["score_seed"]).standard_normal((1000, 2000)).astype(np.float32),
+                  tr, va, te))
+    for name, sc, trl, val, tel in cases:
+        U, I = sc.shape
+        e = _engine(model="bprmf", num_users=U, num_items=I, embed_k=4, optimizer="sgd", max_batch=8)
+        e.bind(Gu=np.zeros((U, 4), np.float32), Gi=np.zeros((I, 4), np.float32), Bi=np.zeros(I, np.float32))
+        csr = lambda lists: tuple(_dev(a) for a in orc.lists_to_csr(lists))
+        S = _dev(sc)
+        want = g[name]["results"]
+        for lists, suf in ((tel, "_t"), (val, "_v")):
+            r = e.eval_users(0, U, S, csr(trl), csr(lists), g[name]["K"]).cpu().numpy()
+            r = r[r[:, 0] >= 0]
+            hr, p, rr, auc, ndcg = r.mean(axis=0).tolist()
+            got = {"hr": hr, "p": p, "r": rr, "auc": auc, "ndcg": ndcg}
+            for key in ("hr", "p", "r", "ndcg") + (("auc",) if suf == "_v" else ()):   # 'auc_t' holds auc_v in the reference
+                assert got[key] == pytest.approx(want[key + suf], abs=1e-12), (name, key + suf)
+
+
+def test_device_eval_multi_item_lists_match_oracle():
+    U, I, K = 50, 80, 5
+    rs = np.random.RandomState(3)
+    sc = rs.standard_normal((U, I)).astype(np.float32)
+    sc[5, :] = 1.0                                                        # all ties
+    trl = [sorted(rs.choice(I, 10, replace=False).tolist()) for _ in range(U)]
+    tel = [rs.choice(I, rs.randint(0, 5), replace=False).tolist() for _ in range(U)]   # 0..4 held-out items, may hit train
+    e = _engine(model="bprmf", num_users=U, num_items=I, embed_k=4, optimizer="sgd", max_batch=8)
+    e.bind(Gu=np.zeros((U, 4), np.float32), Gi=np.zeros((I, 4), np.float32), Bi=np.zeros(I, np.float32))
+    csr = lambda lists: tuple(_dev(a) for a in orc.lists_to_csr(lists))
+    r = e.eval_users(0, U, _dev(sc), csr(trl), csr(tel), K).cpu().numpy()
+    assert (r[[u for u in range(U) if not tel[u]], 0] == -1).all()
+    want = orc.evaluate(sc, trl, None, tel, K)
+    r = r[r[:, 0] >= 0]
+    for c, key in enumerate(("hr_t", "p_t", "r_t", "auc_t", "ndcg_t")):
+        assert r[:, c].mean() == pytest.approx(want[key], abs=1e-12), key
