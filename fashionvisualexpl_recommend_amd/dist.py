@@ -33,15 +33,17 @@ class UserRowExchange:
         # gloo has no all_to_all for device tensors: stage through the host in that case (test mode only)
         self.host_staged = dist.get_backend(group) != "nccl"
 
-    def _a2a(self, inp, in_splits, out_splits):
+    def _a2a(self, inp, in_splits, out_splits, async_op=False):
+        """all_to_all_single with split lists.  async_op: returns (out, work); the collective then runs on the
+        communicator's stream beside whatever the caller enqueues next, until work.wait() (nccl only)."""
         out = inp.new_empty((sum(out_splits),) + tuple(inp.shape[1:]))
         if self.host_staged and inp.is_cuda:
             o, i = out.cpu(), inp.cpu()
             dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
             out.copy_(o)
-        else:
-            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
-        return out
+            return (out, None) if async_op else out
+        work = dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group, async_op=async_op)
+        return (out, work) if async_op else out
 
     def plan(self, u_global):
         """u_global: int tensor [B] of global user ids used by this rank's batch.
@@ -63,16 +65,25 @@ class UserRowExchange:
         recv_local_idx = self._a2a(local, send_counts, recv_counts)
         return order, send_counts, recv_counts, recv_local_idx
 
-    def fetch(self, shard_tables, recv_local_idx, send_counts, recv_counts):
-        """Owners gather the requested rows of each shard table and send them back; returns the fetched rows in
-        batch-sorted order, one tensor per table."""
+    def fetch(self, shard_tables, recv_local_idx, send_counts, recv_counts, async_op=False):
+        """Owners gather the requested rows of the shard tables (concatenated column-wise: ONE collective) and send
+        them back; returns the fetched rows in batch-sorted order, one tensor per table (views of one buffer).
+        async_op: returns (tensors, work) -- call work.wait() (if not None) before using them."""
         idx = recv_local_idx.long()
-        return [self._a2a(t.index_select(0, idx), recv_counts, send_counts) for t in shard_tables]
+        widths = [t.shape[1] for t in shard_tables]
+        packed = torch.cat([t.index_select(0, idx) for t in shard_tables], dim=1) if len(shard_tables) > 1 \
+            else shard_tables[0].index_select(0, idx)
+        res = self._a2a(packed, recv_counts, send_counts, async_op=async_op)
+        out, work = res if async_op else (res, None)
+        parts = list(torch.split(out, widths, dim=1))
+        return (parts, work) if async_op else parts
 
     def give_back(self, grad_rows, send_counts, recv_counts):
-        """Send per-row gradients (batch-sorted order) to the owners; returns the rows each owner received, aligned
-        with the recv_local_idx of plan()."""
-        return [self._a2a(g, send_counts, recv_counts) for g in grad_rows]
+        """Send per-row gradients (batch-sorted order, concatenated column-wise: ONE collective) to the owners; returns
+        the rows each owner received, aligned with the recv_local_idx of plan()."""
+        widths = [g.shape[1] for g in grad_rows]
+        packed = torch.cat(list(grad_rows), dim=1) if len(grad_rows) > 1 else grad_rows[0]
+        return list(torch.split(self._a2a(packed, send_counts, recv_counts), widths, dim=1))
 
 
 class ItemShardedVBPR:
@@ -102,8 +113,10 @@ class ItemShardedVBPR:
         """One global batch-synchronous step; every rank calls it with its own local batch (int32 device tensors)."""
         B = u_global.numel()
         order, sc, rc, ridx = self.x.plan(u_global)
-        self.eng.step_project()                                   # P = F.[E|Bp]: independent of the user rows
-        gu, tu = self.x.fetch([self.Gu_shard, self.Tu_shard], ridx, sc, rc)
+        (gu, tu), work = self.x.fetch([self.Gu_shard, self.Tu_shard], ridx, sc, rc, async_op=True)
+        self.eng.step_project()                                   # P = F.[E|Bp] runs beside the row fetch (xGMI)
+        if work is not None:
+            work.wait()
         self.stage_Gu[:B].copy_(gu)
         self.stage_Tu[:B].copy_(tu)
         i_s, j_s = i_local[order].contiguous(), j_local[order].contiguous()
