@@ -214,11 +214,20 @@ def main():
             }
         else:
             kern_bytes = {"triplet_grad": B * (24 * w["k"] + 28), "apply": B * 36 * w["k"]}
+        # HBM bytes per launch from PMC counters, measured offline with scripts/pmc.sh on this same workload and
+        # committed under profiles/ (bench.py itself cannot run under rocprofv3 --pmc); null when not available
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            if args.workload == "c2" and B == WORKLOADS["c2"]["B"] and dom in pt:
+                traffic = pt[dom]["hbm_bytes"]
+        except Exception:
+            traffic = None
         rl = None
         if dom in kern_bytes:
             ach = kern_bytes[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
             rl = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": kern_bytes[dom],
+                  "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": kern_bytes[dom],
                   "avg_ms": kernels[dom]["avg_ms"]}
         out = {
             "metric": "BPR triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
