@@ -883,6 +883,146 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v7: v6 with TWO chunks in flight (three register sets, two LDS buffers for B).  v6 keeps one chunk
+// (32 KB of feature rows per workgroup) in flight per ~3.4 us round trip; with two, the same round trip carries
+// twice the bytes.  Step for chunk c (register set c%3, LDS buffer c&1):
+//   issue chunk c+2 -> set (c+2)%3 | vmcnt(2*NALL): A(c) landed | MFMA chunk c | vmcnt(2*NALL-NT): B(c+1) landed
+//   | park B(c+1) in the other LDS buffer | barrier
+// Static register naming needs a body of lcm(2,3) = 6 chunks; REM = nch % 6 in {0,2,4} trailing chunks are
+// straight-line code selected on the host (no device branch may sit between an asm load and its wait, see v6).
+// Prefetches past the last chunk re-read chunk nch-1 (never consumed).
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int MT, int REM>
+__global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void k_proj_fwd_bf16_v7(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                             int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                             float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
+  constexpr int BSS = KC + 16;
+  constexpr int KS = KC / 32;
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
+  const int nch = D / KC;
+  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
+  auto kof = [&](int c) { if (c >= nch) c = nch - 1; int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4 b0[NT], b1[NT], b2[NT], a0[KS][MT], a1[KS][MT], a2[KS][MT];
+  constexpr int NALL = NT + KS * MT;
+#define V7_ISSUE(c_, BR, AR)                                                                                          \
+  {                                                                                                                   \
+    const int k1 = kof(c_);                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);      \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
+  }
+#define V7_PARK(buf_, BR, NWAIT)                                                                                      \
+  {                                                                                                                   \
+    asm_vmcnt<NWAIT>();                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_tie(BR[t]);                                                    \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
+        *reinterpret_cast<i32x4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
+  }
+#define V7_COMPUTE(buf_, AR, NWAIT)                                                                                   \
+  {                                                                                                                   \
+    asm_vmcnt<NWAIT>();                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        asm_tie(AR[ks][mt]);                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][(nt * 16 + r) * BSS + ks * 32 + q * 8]);         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[ks][mt]), b,          \
+                                                                 acc[mt][nt], 0, 0, 0);                               \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  // one pipeline step for chunk c_: ANEW/BNEW = set of chunk c_+2, ACUR = set of chunk c_, BNEXT = set of chunk c_+1
+#define V7_STEP(c_, ANEW, BNEW, ACUR, BNEXT, bufcur_)                                                                 \
+  V7_ISSUE((c_) + 2, BNEW, ANEW)                                                                                      \
+  V7_COMPUTE(bufcur_, ACUR, 2 * NALL)                                                                                 \
+  V7_PARK(1 - (bufcur_), BNEXT, 2 * NALL - NT)                                                                        \
+  __syncthreads();
+  V7_ISSUE(0, b0, a0)
+  V7_ISSUE(1, b1, a1)
+  V7_PARK(0, b0, 2 * NALL - NT)
+  __syncthreads();
+  // REM = nch % 6 leading chunks are peeled in FRONT of the loop (peeling them behind it made the compiler spill);
+  // the loop body then starts in rotation state (REM % 3, REM & 1).
+  int c = 0;
+  if (REM == 0) {
+    for (; c + 6 <= nch; c += 6) {
+      V7_STEP(c + 0, a2, b2, a0, b1, 0)
+      V7_STEP(c + 1, a0, b0, a1, b2, 1)
+      V7_STEP(c + 2, a1, b1, a2, b0, 0)
+      V7_STEP(c + 3, a2, b2, a0, b1, 1)
+      V7_STEP(c + 4, a0, b0, a1, b2, 0)
+      V7_STEP(c + 5, a1, b1, a2, b0, 1)
+    }
+  } else if (REM == 2) {
+    V7_STEP(0, a2, b2, a0, b1, 0)
+    V7_STEP(1, a0, b0, a1, b2, 1)
+    for (c = 2; c + 6 <= nch; c += 6) {
+      V7_STEP(c + 0, a1, b1, a2, b0, 0)
+      V7_STEP(c + 1, a2, b2, a0, b1, 1)
+      V7_STEP(c + 2, a0, b0, a1, b2, 0)
+      V7_STEP(c + 3, a1, b1, a2, b0, 1)
+      V7_STEP(c + 4, a2, b2, a0, b1, 0)
+      V7_STEP(c + 5, a0, b0, a1, b2, 1)
+    }
+  } else {
+    V7_STEP(0, a2, b2, a0, b1, 0)
+    V7_STEP(1, a0, b0, a1, b2, 1)
+    V7_STEP(2, a1, b1, a2, b0, 0)
+    V7_STEP(3, a2, b2, a0, b1, 1)
+    for (c = 4; c + 6 <= nch; c += 6) {
+      V7_STEP(c + 0, a0, b0, a1, b2, 0)
+      V7_STEP(c + 1, a1, b1, a2, b0, 1)
+      V7_STEP(c + 2, a2, b2, a0, b1, 0)
+      V7_STEP(c + 3, a0, b0, a1, b2, 1)
+      V7_STEP(c + 4, a1, b1, a2, b0, 0)
+      V7_STEP(c + 5, a2, b2, a0, b1, 1)
+    }
+  }
+  asm_vmcnt<0>();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { asm_tie(a0[ks][mt]); asm_tie(a1[ks][mt]); asm_tie(a2[ks][mt]); }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { asm_tie(b0[t]); asm_tie(b1[t]); asm_tie(b2[t]); }
+#undef V7_STEP
+#undef V7_ISSUE
+#undef V7_PARK
+#undef V7_COMPUTE
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = row0 + mt * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // backward v4: v3 with TWO item tiles in flight per workgroup (two named register sets; the commit of tile t only
 // waits for its own loads because vmcnt retires in issue order, so tile t+1 stays in flight across the barriers).
@@ -1033,6 +1173,8 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
   }
 }
 
+extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
+
 #define FWD_ARGS (const uint16_t *)h->t.F, rows, (int)nrows, h->cfg.num_items, h->cfg.feat_dim, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
@@ -1043,19 +1185,26 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   const int rows_per_wg = 4 * MT * 16;
   dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
-  if (v >= 6) {   // 6 = v4 KC 256, 2 row tiles per wave (1 above NT 9); 7 = v4 KC 256, 1 row tile per wave
-    if (h->cfg.feat_dim % 256 == 0) {
-      constexpr int MT4 = NT <= 9 ? 2 : 1;
+  if (v >= 6) {   // 6 = v7 (two chunks in flight), 2 row tiles per wave (1 above NT 9); 7 = v7, 1 row tile per wave
+    constexpr int MT7 = NT <= 9 ? 2 : 1;
+    const int rem = (h->cfg.feat_dim / KC) % 6;
+    if (h->cfg.feat_dim % 256 == 0 && (h->cfg.feat_dim / KC) >= 6 && bprx_variant_safe(7, NT, v == 6 ? MT7 : 1, rem)) {
+#define L7(MTV, REMV) hipLaunchKernelGGL((k_proj_fwd_bf16_v7<NT, MTV, REMV>), g7, dim3(256), 0, s, FWD_ARGS, stg)
       if (v == 6) {
-        dim3 g4((unsigned)((nrows + 64 * MT4 - 1) / (64 * MT4)));
-        hipLaunchKernelGGL((k_proj_fwd_bf16_v4<NT, MT4, 256>), g4, dim3(256), 0, s, FWD_ARGS, stg);
+        dim3 g7((unsigned)((nrows + 64 * MT7 - 1) / (64 * MT7)));
+        if (rem == 0) L7(MT7, 0); else if (rem == 2) L7(MT7, 2); else L7(MT7, 4);
       } else {
-        dim3 g4((unsigned)((nrows + 63) / 64));
-        hipLaunchKernelGGL((k_proj_fwd_bf16_v4<NT, 1, 256>), g4, dim3(256), 0, s, FWD_ARGS, stg);
+        dim3 g7((unsigned)((nrows + 63) / 64));
+        if (rem == 0) L7(1, 0); else if (rem == 2) L7(1, 2); else L7(1, 4);
       }
+#undef L7
       return 0;
     }
-    hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+    // not verified spill-free: the v6 pipeline if that one is, else the plain kernel
+    if (h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(6, NT, MTD, 0))
+      hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+    else
+      hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
     return 0;
   }
   if (v >= 4) {   // 4 = v3 (LDS-staged A) 64 rows per workgroup, 5 = v3 128 rows per workgroup
@@ -1067,7 +1216,8 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   }
   if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-  else if (h->cfg.feat_dim % 256 != 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), dim3((unsigned)((nrows + 4 * MTD * 16 - 1) / (4 * MTD * 16))), dim3(256), 0, s, FWD_ARGS, stg);
+  else if (h->cfg.feat_dim % 256 != 0 || !bprx_variant_safe(6, NT, v == 2 ? MTD : 1, 0))
+    hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), dim3((unsigned)((nrows + 4 * MTD * 16 - 1) / (4 * MTD * 16))), dim3(256), 0, s, FWD_ARGS, stg);
   else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   else hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   return 0;
