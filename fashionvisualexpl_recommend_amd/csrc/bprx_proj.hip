@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, co
 // B ([E|Bp]^T chunk, shared by the 4 waves and re-read from L2 by every workgroup) is staged through LDS.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int KC = 128;          // k-chunk staged per barrier pair
-constexpr int BS_STRIDE = KC + 8;  // bf16 elements; 272-B rows keep ds_read_b128 nearly conflict-free
+constexpr int BS_STRIDE = KC + 8;  // bf16 elements; 272-B rows keep ds_read_b128 nearly conflict-free (v1)
 
 template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
@@ -208,280 +208,6 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16(const uint16_t *__restric
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// forward v2: the same tiling with software pipelining.  While chunk c is multiplied, the loads of chunk c+1
-// (A rows: HBM -> VGPR, B: L2 -> VGPR) are already in flight; B reaches LDS through a second buffer, so a
-// chunk costs ONE barrier and no wave ever waits for memory with nothing outstanding.
-// ------------------------------------------------------------------------------------------------------------
-template <int NT, int MT>
-__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v2(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag) {
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BS_STRIDE];
-  constexpr int KS = KC / 32;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
-  const uint16_t *arow[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int t = row0 + mt * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
-  }
-  // B staging: thread owns NT 16-byte pieces of the [NT*16][KC] chunk: piece t -> row n = t*16 + tid/16, k = (tid%16)*8
-  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
-  uint4 breg[NT];
-  bf16x8 a_cur[KS][MT], a_nxt[KS][MT];
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + bn, bk, NT * 16)]);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_cur[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + ks * 32);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&Bs[0][(t * 16 + bn) * BS_STRIDE + bk]) = breg[t];
-  __syncthreads();
-  const int nch = D / KC;
-  for (int c = 0; c < nch; ++c) {
-    const bool more = c + 1 < nch;
-    if (more) {
-      const int k1 = (c + 1) * KC;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a_nxt[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k1 + ks * 32);
-    }
-    const uint16_t *bs = Bs[c & 1];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&bs[(nt * 16 + r) * BS_STRIDE + ks * 32 + q * 8]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[ks][mt], b, acc[mt][nt], 0, 0, 0);
-      }
-    }
-    if (more) {
-      uint16_t *bd = Bs[(c + 1) & 1];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&bd[(t * 16 + bn) * BS_STRIDE + bk]) = breg[t];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a_cur[ks][mt] = a_nxt[ks][mt];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = row0 + mt * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// backward v2: MC feature columns x BTV items per tile, next tile's F rows and W rows prefetched into registers
-// while the current tile is multiplied.  `descend` walks the items from the end of the split to its start: the
-// forward pass streams F upwards, so the backward pass meets the rows the Infinity Cache still holds first.
-// ------------------------------------------------------------------------------------------------------------
-template <int NT, int MC, int BTV>
-__global__ __launch_bounds__(256) void k_proj_bwd_bf16_v2(const uint16_t *__restrict__ F, int nrows, int D,
-                                                          const float *__restrict__ W, int PS, float *__restrict__ part,
-                                                          int rows_per_split, int descend) {
-  constexpr int WS = WsStride<NT>::value;
-  constexpr int FSS = MC + 16;                       // bf16 elements per LDS row of the F tile (32 B over a 256-B multiple)
-  constexpr int MTW = MC / 64;                       // 16-column M tiles per wave (4 waves)
-  constexpr int FPT = BTV * (MC / 8) / 256;          // 16-B F pieces per thread and tile
-  constexpr int WPT = (BTV * NT * 4 + 255) / 256;    // float4 W pieces per thread and tile
-  __shared__ __attribute__((aligned(16))) uint16_t Fs[BTV * FSS];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[BTV * WS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
-  const int m0 = blockIdx.x * MC;
-  const int tbeg = blockIdx.y * rows_per_split;
-  int tend = tbeg + rows_per_split;
-  if (tend > nrows) tend = nrows;
-  const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
-  f32x4 acc[MTW][NT];
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint4 freg[FPT];
-  float4 wreg[WPT];
-  auto issue = [&](int tile) {
-    const int t0 = tbeg + (descend ? (ntiles - 1 - tile) : tile) * BTV;
-#pragma unroll
-    for (int x = 0; x < FPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / (MC / 8), ch = idx % (MC / 8), t = t0 + tr;
-      freg[x] = make_uint4(0, 0, 0, 0);
-      if (t < tend) freg[x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
-    }
-#pragma unroll
-    for (int x = 0; x < WPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / (NT * 4), c4 = idx % (NT * 4), t = t0 + tr;
-      wreg[x] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < BTV * NT * 4 && t < tend) wreg[x] = *reinterpret_cast<const float4 *>(W + (size_t)t * PS + c4 * 4);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int x = 0; x < FPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / (MC / 8), ch = idx % (MC / 8);
-      *reinterpret_cast<uint4 *>(&Fs[tr * FSS + ch * 8]) = freg[x];
-    }
-#pragma unroll
-    for (int x = 0; x < WPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / (NT * 4), c4 = idx % (NT * 4);
-      if (idx < BTV * NT * 4) {
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(wreg[x].x) | ((uint32_t)f2bf(wreg[x].y) << 16);
-        pk.y = (uint32_t)f2bf(wreg[x].z) | ((uint32_t)f2bf(wreg[x].w) << 16);
-        *reinterpret_cast<uint2 *>(&Ws[tr * WS + c4 * 4]) = pk;
-      }
-    }
-  };
-  if (ntiles > 0) issue(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();                                  // everyone is done reading the previous tile
-    commit();
-    __syncthreads();
-    if (tile + 1 < ntiles) issue(tile + 1);           // in flight during the MFMAs below
-#pragma unroll
-    for (int kk = 0; kk < BTV / 32; ++kk) {
-      bf16x8 a[MTW];
-#pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
-        const int col = (w * MTW + mt) * 16 + 4 * p;
-        bf16x4 lo = lds_tr16(&Fs[(kk * 32 + 8 * g + qq) * FSS + col]);
-        bf16x4 hi = lds_tr16(&Fs[(kk * 32 + 8 * g + qq + 4) * FSS + col]);
-        a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = nt * 16 + 4 * p;
-        bf16x4 lo = lds_tr16(&Ws[(kk * 32 + 8 * g + qq) * WS + col]);
-        bf16x4 hi = lds_tr16(&Ws[(kk * 32 + 8 * g + qq + 4) * WS + col]);
-        const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
-      }
-    }
-  }
-  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int m = (w * MTW + mt) * 16 + g * 4 + reg;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// forward v3: BOTH operands staged through LDS with row-contiguous (fully coalesced) global loads -- a wave
-// instruction reads 4 rows x 256 B instead of 16 rows x 64 B in MFMA fragment order (fragment-shaped loads
-// quadruple the request count of the texture addresser; measured 2.6 TB/s).  Next chunk prefetched into
-// registers while the current one is multiplied; 288-B LDS rows make every ds_read_b128 conflict-free.
-// Workgroup = 4 waves x MT row tiles = 64*MT feature rows.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int LS3 = KC + 16;   // 288-B rows: bank = 4*(2r + q) mod 64 is injective over each ds_read_b128 lane group
-
-template <int NT, int MT>
-__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v3(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
-  constexpr int RW = 64 * MT;                       // rows per workgroup
-  constexpr int APT = RW * 16 / 256;                // 16-B A pieces per thread and chunk (= 4*MT)
-  __shared__ __attribute__((aligned(16))) uint16_t As[RW * LS3];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * LS3];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = blockIdx.x * RW;
-  // staging role: piece x -> tile row (x*16 + tid/16), 16-B chunk tid%16
-  const int sr = threadIdx.x >> 4, sc = (threadIdx.x & 15) * 8;
-  const uint16_t *asrc[APT];
-#pragma unroll
-  for (int x = 0; x < APT; ++x) {
-    int t = row0 + x * 16 + sr;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    asrc[x] = F + (size_t)item * D + sc;
-  }
-  uint4 areg[APT], breg[NT];
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nch = D / KC;
-  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;   // see k_proj_fwd_bf16
-  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
-  {
-    const int k1 = kof(0);
-#pragma unroll
-    for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + sr, k1 + sc, NT * 16)]);
-  }
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();                                  // previous chunk fully consumed
-#pragma unroll
-    for (int x = 0; x < APT; ++x) *reinterpret_cast<uint4 *>(&As[(x * 16 + sr) * LS3 + sc]) = areg[x];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4 *>(&Bs[(t * 16 + sr) * LS3 + sc]) = breg[t];
-    __syncthreads();
-    if (c + 1 < nch) {                                // next chunk in flight during the MFMAs
-      const int k1 = kof(c + 1);
-#pragma unroll
-      for (int x = 0; x < APT; ++x) areg[x] = *reinterpret_cast<const uint4 *>(asrc[x] + k1);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) breg[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + sr, k1 + sc, NT * 16)]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KC; ks += 32) {
-      bf16x8 a[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        a[mt] = *reinterpret_cast<const bf16x8 *>(&As[((w * MT + mt) * 16 + r) * LS3 + ks + q * 8]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * LS3 + ks + q * 8]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = row0 + (w * MT + mt) * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
-      }
-    }
-}
-
 // Wb (bf16 [I][PS]) = W (fp32), and W is re-zeroed for the next step in the same pass.
 __global__ __launch_bounds__(256) void k_cast_W(float *__restrict__ W, uint16_t *__restrict__ Wb, size_t n4) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
@@ -598,178 +324,10 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16_v3(const uint16_t *__rest
 
 
 // ------------------------------------------------------------------------------------------------------------
-// forward v4.  Measured on v1-v3: these kernels are LATENCY-bound, not bandwidth-bound -- a workgroup has one
-// k-chunk of its rows in flight per memory round trip (~4.7 us under load), so the chip moves
-// (resident rows x chunk bytes) per round trip: 50K rows x 256 B = 12.8 MB -> 2.7 TB/s.  v4 widens the chunk to
-// KCV = 256 columns (512 B per row, 16 loads in flight per wave) and issues the [E|Bp]^T chunk and the feature-row
-// chunk TOGETHER, so one round trip serves both.
-// ------------------------------------------------------------------------------------------------------------
-template <int NT, int MT, int KCV>
-__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v4(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
-  constexpr int BSS = KCV + 16;                      // 32-B pad: conflict-free ds_read_b128 (see LS3)
-  constexpr int KS = KCV / 32;
-  constexpr int LPR = KCV / 8;                       // 16-B pieces per staged B row
-  constexpr int BPT = NT * 16 * LPR / 256;           // pieces per thread
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * BSS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
-  const uint16_t *arow[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int t = row0 + mt * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
-  }
-  const int bn = threadIdx.x / LPR, bk = (threadIdx.x % LPR) * 8;     // piece x -> B row bn + x*(256/LPR)
-  constexpr int BROWS = 256 / LPR;
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nch = D / KCV;
-  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
-  for (int c = 0; c < nch; ++c) {
-    int ce = c + cshift;
-    if (ce >= nch) ce -= nch;
-    const int k0 = ce * KCV;
-    uint4 breg[BPT];
-    bf16x8 a[KS][MT];
-#pragma unroll
-    for (int x = 0; x < BPT; ++x) breg[x] = *reinterpret_cast<const uint4 *>(&Et[et_idx(bn + x * BROWS, k0 + bk, NT * 16)]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k0 + ks * 32);
-    __syncthreads();                                  // previous chunk's B fully consumed
-#pragma unroll
-    for (int x = 0; x < BPT; ++x) *reinterpret_cast<uint4 *>(&Bs[(bn + x * BROWS) * BSS + bk]) = breg[x];
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * BSS + ks * 32 + q * 8]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][mt], b, acc[mt][nt], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = row0 + mt * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
-      }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// forward v5: explicit ping-pong software pipeline (two named register sets, loop unrolled by two, scheduling
-// fences between the phases) -- the v2 source was "un-pipelined" by the compiler (its MFMAs waited on the loads
-// issued in the same iteration).  Per chunk: [issue loads of chunk c+1 into the idle set] -> [MFMA chunk c from
-// the live set + LDS] -> [park chunk c+1's B rows in the other LDS buffer] -> ONE barrier.
-// ------------------------------------------------------------------------------------------------------------
-template <int NT, int MT>
-__global__ __launch_bounds__(256) void k_proj_fwd_bf16_v5(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
-  constexpr int BSS = KC + 16;
-  constexpr int KS = KC / 32;
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
-  const uint16_t *arow[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int t = row0 + mt * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
-  }
-  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
-  const int nch = D / KC;
-  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
-  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint4 bX[NT], bY[NT];
-  bf16x8 aX[KS][MT], aY[KS][MT];
-  // (macros, not lambdas: register arrays passed by reference ended up in scratch memory)
-#define V5_ISSUE(c_, BR, AR)                                                                                          \
-  {                                                                                                                   \
-    const int k1 = kof(c_);                                                                                           \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
-        BR[t] = *reinterpret_cast<const uint4 *>(&Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);                         \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        AR[ks][mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + k1 + ks * 32);                                      \
-  }
-#define V5_PARK(buf_, BR)                                                                                             \
-  {                                                                                                                   \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
-        *reinterpret_cast<uint4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
-  }
-#define V5_COMPUTE(buf_, AR)                                                                                          \
-  {                                                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][(nt * 16 + r) * BSS + ks * 32 + q * 8]);         \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AR[ks][mt], b, acc[mt][nt], 0, 0, 0);               \
-      }                                                                                                               \
-    }                                                                                                                 \
-  }
-  V5_ISSUE(0, bX, aX)
-  V5_PARK(0, bX)
-  __syncthreads();
-  for (int c = 0; c < nch; c += 2) {            // nch is even (D % 256 == 0 is required by the launcher)
-    V5_ISSUE(c + 1, bY, aY)
-    __builtin_amdgcn_sched_barrier(0);
-    V5_COMPUTE(0, aX)
-    __builtin_amdgcn_sched_barrier(0);
-    V5_PARK(1, bY)
-    __syncthreads();
-    if (c + 2 < nch) V5_ISSUE(c + 2, bX, aX)
-    __builtin_amdgcn_sched_barrier(0);
-    V5_COMPUTE(1, aY)
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 < nch) V5_PARK(0, bX)
-    __syncthreads();
-  }
-#undef V5_ISSUE
-#undef V5_PARK
-#undef V5_COMPUTE
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = row0 + mt * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
-      }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// forward v6: the v5 ping-pong pipeline with its global loads and waits written as inline asm.  hipcc kept
-// re-timing the C++ version (it sank the [E|Bp]^T loads next to their LDS store and waited on same-iteration loads
-// inside the MFMA block), so every chunk still paid a full memory round trip.  Here every loop load is an asm
+// forward v6: explicit ping-pong software pipeline (two named register sets, loop unrolled by two) whose global loads
+// and waits are written as inline asm.  hipcc kept re-timing every C++ formulation of the same pipeline (it sank the
+// [E|Bp]^T loads next to their LDS store and waited on same-iteration loads inside the MFMA block; see
+// profiles/r01_sweeps.md), so every chunk still paid a full memory round trip.  Here every loop load is an asm
 // `global_load_dwordx4`; the compiler sees no VMEM event, inserts no vmcnt of its own, and the two counted waits per
 // half-iteration are placed by hand (vmcnt retires in issue order: B pieces first, then the A fragments):
 //   before parking chunk c+1's B pieces:  vmcnt(KS*MT)        -> only the A fragments of c+1 stay in flight
@@ -884,249 +442,6 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// forward v7: v6 with TWO chunks in flight (three register sets, two LDS buffers for B).  v6 keeps one chunk
-// (32 KB of feature rows per workgroup) in flight per ~3.4 us round trip; with two, the same round trip carries
-// twice the bytes.  Step for chunk c (register set c%3, LDS buffer c&1):
-//   issue chunk c+2 -> set (c+2)%3 | vmcnt(2*NALL): A(c) landed | MFMA chunk c | vmcnt(2*NALL-NT): B(c+1) landed
-//   | park B(c+1) in the other LDS buffer | barrier
-// Static register naming needs a body of lcm(2,3) = 6 chunks; REM = nch % 6 in {0,2,4} trailing chunks are
-// straight-line code selected on the host (no device branch may sit between an asm load and its wait, see v6).
-// Prefetches past the last chunk re-read chunk nch-1 (never consumed).
-// ------------------------------------------------------------------------------------------------------------
-template <int NT, int MT, int REM>
-__global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void k_proj_fwd_bf16_v7(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                             int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                             float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
-  constexpr int BSS = KC + 16;
-  constexpr int KS = KC / 32;
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
-  const uint16_t *arow[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int t = row0 + mt * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
-  const int nch = D / KC;
-  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
-  auto kof = [&](int c) { if (c >= nch) c = nch - 1; int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x4 b0[NT], b1[NT], b2[NT], a0[KS][MT], a1[KS][MT], a2[KS][MT];
-  constexpr int NALL = NT + KS * MT;
-#define V7_ISSUE(c_, BR, AR)                                                                                          \
-  {                                                                                                                   \
-    const int k1 = kof(c_);                                                                                           \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);      \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
-  }
-#define V7_PARK(buf_, BR, NWAIT)                                                                                      \
-  {                                                                                                                   \
-    asm_vmcnt<NWAIT>();                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_tie(BR[t]);                                                    \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
-        *reinterpret_cast<i32x4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
-  }
-#define V7_COMPUTE(buf_, AR, NWAIT)                                                                                   \
-  {                                                                                                                   \
-    asm_vmcnt<NWAIT>();                                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_tie(AR[ks][mt]);                                                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][(nt * 16 + r) * BSS + ks * 32 + q * 8]);         \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[ks][mt]), b,          \
-                                                                 acc[mt][nt], 0, 0, 0);                               \
-      }                                                                                                               \
-    }                                                                                                                 \
-  }
-  // one pipeline step for chunk c_: ANEW/BNEW = set of chunk c_+2, ACUR = set of chunk c_, BNEXT = set of chunk c_+1
-#define V7_STEP(c_, ANEW, BNEW, ACUR, BNEXT, bufcur_)                                                                 \
-  V7_ISSUE((c_) + 2, BNEW, ANEW)                                                                                      \
-  V7_COMPUTE(bufcur_, ACUR, 2 * NALL)                                                                                 \
-  V7_PARK(1 - (bufcur_), BNEXT, 2 * NALL - NT)                                                                        \
-  __syncthreads();
-  V7_ISSUE(0, b0, a0)
-  V7_ISSUE(1, b1, a1)
-  V7_PARK(0, b0, 2 * NALL - NT)
-  __syncthreads();
-  // REM = nch % 6 leading chunks are peeled in FRONT of the loop (peeling them behind it made the compiler spill);
-  // the loop body then starts in rotation state (REM % 3, REM & 1).
-  int c = 0;
-  if (REM == 0) {
-    for (; c + 6 <= nch; c += 6) {
-      V7_STEP(c + 0, a2, b2, a0, b1, 0)
-      V7_STEP(c + 1, a0, b0, a1, b2, 1)
-      V7_STEP(c + 2, a1, b1, a2, b0, 0)
-      V7_STEP(c + 3, a2, b2, a0, b1, 1)
-      V7_STEP(c + 4, a0, b0, a1, b2, 0)
-      V7_STEP(c + 5, a1, b1, a2, b0, 1)
-    }
-  } else if (REM == 2) {
-    V7_STEP(0, a2, b2, a0, b1, 0)
-    V7_STEP(1, a0, b0, a1, b2, 1)
-    for (c = 2; c + 6 <= nch; c += 6) {
-      V7_STEP(c + 0, a1, b1, a2, b0, 0)
-      V7_STEP(c + 1, a2, b2, a0, b1, 1)
-      V7_STEP(c + 2, a0, b0, a1, b2, 0)
-      V7_STEP(c + 3, a1, b1, a2, b0, 1)
-      V7_STEP(c + 4, a2, b2, a0, b1, 0)
-      V7_STEP(c + 5, a0, b0, a1, b2, 1)
-    }
-  } else {
-    V7_STEP(0, a2, b2, a0, b1, 0)
-    V7_STEP(1, a0, b0, a1, b2, 1)
-    V7_STEP(2, a1, b1, a2, b0, 0)
-    V7_STEP(3, a2, b2, a0, b1, 1)
-    for (c = 4; c + 6 <= nch; c += 6) {
-      V7_STEP(c + 0, a0, b0, a1, b2, 0)
-      V7_STEP(c + 1, a1, b1, a2, b0, 1)
-      V7_STEP(c + 2, a2, b2, a0, b1, 0)
-      V7_STEP(c + 3, a0, b0, a1, b2, 1)
-      V7_STEP(c + 4, a1, b1, a2, b0, 0)
-      V7_STEP(c + 5, a2, b2, a0, b1, 1)
-    }
-  }
-  asm_vmcnt<0>();
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { asm_tie(a0[ks][mt]); asm_tie(a1[ks][mt]); asm_tie(a2[ks][mt]); }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { asm_tie(b0[t]); asm_tie(b1[t]); asm_tie(b2[t]); }
-#undef V7_STEP
-#undef V7_ISSUE
-#undef V7_PARK
-#undef V7_COMPUTE
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = row0 + mt * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// backward v4: v3 with TWO item tiles in flight per workgroup (two named register sets; the commit of tile t only
-// waits for its own loads because vmcnt retires in issue order, so tile t+1 stays in flight across the barriers).
-// ------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_proj_bwd_bf16_v4(const uint16_t *__restrict__ F, int nrows, int D,
-                                                          const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
-                                                          int rows_per_split, int descend) {
-  constexpr int BTV = 32;
-  constexpr int FSB = 288;
-  constexpr int WSB = WsStride3<NT>::bytes;
-  constexpr int FPT = BTV * 16 / 256;                // 2
-  constexpr int WCH = NT * 2;
-  constexpr int WPT = (BTV * WCH + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char Fs[BTV * FSB];
-  __shared__ __attribute__((aligned(16))) unsigned char Ws[BTV * WSB];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
-  const int m0 = blockIdx.x * 128;
-  const int tbeg = blockIdx.y * rows_per_split;
-  int tend = tbeg + rows_per_split;
-  if (tend > nrows) tend = nrows;
-  const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint4 fX[FPT], wX[WPT], fY[FPT], wY[WPT];
-  auto issue = [&](int tile, uint4 (&fr)[FPT], uint4 (&wr)[WPT]) {
-    const int t0 = tbeg + (descend ? (ntiles - 1 - tile) : tile) * BTV;
-#pragma unroll
-    for (int x = 0; x < FPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15, t = t0 + tr;
-      fr[x] = make_uint4(0, 0, 0, 0);
-      if (tile < ntiles && t < tend) fr[x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
-    }
-#pragma unroll
-    for (int x = 0; x < WPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH, t = t0 + tr;
-      wr[x] = make_uint4(0, 0, 0, 0);
-      if (tile < ntiles && idx < BTV * WCH && t < tend) wr[x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);
-    }
-  };
-  auto commit = [&](uint4 (&fr)[FPT], uint4 (&wr)[WPT]) {
-#pragma unroll
-    for (int x = 0; x < FPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15;
-      *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = fr[x];
-    }
-#pragma unroll
-    for (int x = 0; x < WPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH;
-      if (idx < BTV * WCH) *reinterpret_cast<uint4 *>(&Ws[tr * WSB + ((tr & 8) << 4) + ch * 16]) = wr[x];
-    }
-  };
-  auto compute = [&]() {
-    const int rlo = 8 * g + qq, rhi = rlo + 4;
-    const int disp = (g & 1) << 7;
-    bf16x8 a[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int cb = (((w * 2 + mt) * 16 + 4 * p) * 2) ^ disp;
-      bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rlo * FSB + cb]));
-      bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rhi * FSB + cb]));
-      a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int cb = (nt * 16 + 4 * p) * 2 + disp;
-      bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rlo * WSB + cb]));
-      bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rhi * WSB + cb]));
-      const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
-    }
-  };
-  issue(0, fX, wX);
-  issue(1, fY, wY);
-  for (int tile = 0; tile < ntiles; tile += 2) {
-    __syncthreads();
-    commit(fX, wX);
-    __syncthreads();
-    issue(tile + 2, fX, wX);
-    compute();
-    if (tile + 1 < ntiles) {
-      __syncthreads();
-      commit(fY, wY);
-      __syncthreads();
-      issue(tile + 3, fY, wY);
-      compute();
-    }
-  }
-  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int m = (w * 2 + mt) * 16 + g * 4 + reg;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
-    }
-}
-
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
                                                       float *__restrict__ dEp) {
@@ -1179,79 +494,43 @@ extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generat
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   constexpr int MTD = NT <= 9 ? 2 : 1;
-  // variants: 0 = v1 (2 barriers per chunk, no prefetch), 1 = v1 with one row tile per wave,
-  //           2 = v2 pipelined, 2 row tiles per wave (1 above NT 9), 3 = v2 pipelined, 1 row tile per wave
-  const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3);   // +8 = staggered chunk order (v1 / v3 / v4); +16/+32: v1 ablations
+  // fwd_variant: 0 = v1 (2 barriers per chunk, nothing overlapped), 1 = v1 with one row tile per wave,
+  //              2 = v6 (asm-pinned ping-pong pipeline), 3 = v6 with one row tile per wave; +8 = staggered chunk order;
+  //              +16 / +32 = v1 timing-only ablations (skip the B / A loads)
+  const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3);
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
-  const int rows_per_wg = 4 * MT * 16;
-  dim3 grid((unsigned)((nrows + rows_per_wg - 1) / rows_per_wg));
-  if (v >= 6) {   // 6 = v7 (two chunks in flight), 2 row tiles per wave (1 above NT 9); 7 = v7, 1 row tile per wave
-    constexpr int MT7 = NT <= 9 ? 2 : 1;
-    const int rem = (h->cfg.feat_dim / KC) % 6;
-    if (h->cfg.feat_dim % 256 == 0 && (h->cfg.feat_dim / KC) >= 6 && bprx_variant_safe(7, NT, v == 6 ? MT7 : 1, rem)) {
-#define L7(MTV, REMV) hipLaunchKernelGGL((k_proj_fwd_bf16_v7<NT, MTV, REMV>), g7, dim3(256), 0, s, FWD_ARGS, stg)
-      if (v == 6) {
-        dim3 g7((unsigned)((nrows + 64 * MT7 - 1) / (64 * MT7)));
-        if (rem == 0) L7(MT7, 0); else if (rem == 2) L7(MT7, 2); else L7(MT7, 4);
-      } else {
-        dim3 g7((unsigned)((nrows + 63) / 64));
-        if (rem == 0) L7(1, 0); else if (rem == 2) L7(1, 2); else L7(1, 4);
-      }
-#undef L7
-      return 0;
-    }
-    // not verified spill-free: the v6 pipeline if that one is, else the plain kernel
-    if (h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(6, NT, MTD, 0))
-      hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-    else
-      hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-    return 0;
-  }
-  if (v >= 4) {   // 4 = v3 (LDS-staged A) 64 rows per workgroup, 5 = v3 128 rows per workgroup
-    const int mt3 = (v == 5 && NT <= 9) ? 2 : 1;
-    dim3 g3((unsigned)((nrows + 64 * mt3 - 1) / (64 * mt3)));
-    if (mt3 == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, (NT <= 9 ? 2 : 1)>), g3, dim3(256), 0, s, FWD_ARGS, stg);
-    else hipLaunchKernelGGL((k_proj_fwd_bf16_v3<NT, 1>), g3, dim3(256), 0, s, FWD_ARGS, stg);
-    return 0;
-  }
-  if (v == 0) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-  else if (v == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-  else if (h->cfg.feat_dim % 256 != 0 || !bprx_variant_safe(6, NT, v == 2 ? MTD : 1, 0))
-    hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), dim3((unsigned)((nrows + 4 * MTD * 16 - 1) / (4 * MTD * 16))), dim3(256), 0, s, FWD_ARGS, stg);
-  else if (v == 2) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-  else hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+  dim3 grid((unsigned)((nrows + 4 * MT * 16 - 1) / (4 * MT * 16)));
+  // the pipelined kernel only where the build verified it spill-free (build.py), and D must hold an even chunk count
+  const bool pipe = (v == 2 || v == 3) && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(6, NT, MT, 0);
+  if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1);
+  else if (pipe) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1);
+  else if (MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+  else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   return 0;
 }
 
 template <int NT>
 int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, I = h->cfg.num_items;
-  // variants: 0 = v1 (128 cols x 32 items, no prefetch); 1 = v2 128x32; 2 = v2 128x64; 3 = v2 64x64; +4 = descending
+  // bwd_variant: 0 = v1 (fp32 W, no prefetch); 8 = v3 (bf16 W, conflict-free LDS image, next tile prefetched),
+  //              9 = v3 with 64-item tiles; +4 = walk the items in descending order
   const int desc = (h->bwd_variant >> 2) & 1;
-  if (h->bwd_variant >= 8) {   // 8 = v3 128 cols x 32 items, 9 = v3 128 x 64, 10 = v4 (two tiles in flight) (+4 = descending)
-    const int v3 = h->bwd_variant & 3, bt3 = v3 == 1 ? 64 : 32;
+  if (h->bwd_variant >= 8) {
+    const int bt3 = (h->bwd_variant & 3) == 1 ? 64 : 32;
     int rps3 = (I + h->SK - 1) / h->SK;
     rps3 = (rps3 + bt3 - 1) / bt3 * bt3;
     const size_t n4 = (size_t)I * h->PS / 4;
     if (!h->item_mode)   // k_item_bin has already written Wb (bf16) itself
       hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
     dim3 g3(D / 128, h->SK);
-    if (v3 == 2) hipLaunchKernelGGL((k_proj_bwd_bf16_v4<NT>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
-    else if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
+    if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
     else hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 64>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
     return 0;
   }
-  const int v = h->bwd_variant & 3;
-  const int mc = (v == 3) ? 64 : 128;
-  const int btv = (v >= 2) ? 64 : 32;
   int rps = (I + h->SK - 1) / h->SK;
-  rps = (rps + btv - 1) / btv * btv;
-  dim3 grid(D / mc, h->SK);
-#define BWD_ARGS (const uint16_t *)h->t.F, I, D, h->W, h->PS, h->part, rps
-  if (v == 0) hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, BWD_ARGS);
-  else if (v == 1) hipLaunchKernelGGL((k_proj_bwd_bf16_v2<NT, 128, 32>), grid, dim3(256), 0, s, BWD_ARGS, desc);
-  else if (v == 2) hipLaunchKernelGGL((k_proj_bwd_bf16_v2<NT, 128, 64>), grid, dim3(256), 0, s, BWD_ARGS, desc);
-  else hipLaunchKernelGGL((k_proj_bwd_bf16_v2<NT, 64, 64>), grid, dim3(256), 0, s, BWD_ARGS, desc);
+  rps = (rps + BT - 1) / BT * BT;
+  dim3 grid(D / 128, h->SK);
+  hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, h->W, h->PS, h->part, rps);
   return 0;
 }
 

@@ -22,8 +22,8 @@ def main():
     g.manual_seed(7)
     batches = [tuple(torch.randint(n, (B,), generator=g, device=dev, dtype=torch.int32) for n in (w["U"], w["I"], w["I"]))
                for _ in range(4)]
-    fwd = [int(x) for x in os.environ.get("SWEEP_FWD", "0,1,2,3").split(",")]
-    bwd = [int(x) for x in os.environ.get("SWEEP_BWD", "0,1,2,3,5,6,7").split(",")]
+    fwd = [int(x) for x in os.environ.get("SWEEP_FWD", "0,8,2,10,3,11").split(",")]
+    bwd = [int(x) for x in os.environ.get("SWEEP_BWD", "0,8,9,12").split(",")]
     sks = [int(x) for x in os.environ.get("SWEEP_SK", "32").split(",")]
     rounds = int(os.environ.get("SWEEP_ROUNDS", "3"))
     steps = int(os.environ.get("SWEEP_STEPS", "8"))
