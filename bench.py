@@ -121,6 +121,10 @@ def main():
     tables = make_state(w, device, 1234 + rank, torch)
     sharded = None
     users_total = w["U"] * world
+    # index ranges the sampler draws from: item-sharded VBPR -> global users, local items;
+    # user-sharded BPRMF -> local users, global items
+    samp_users = users_total if w["model"] == "vbpr" else w["U"]
+    samp_items = w["I"] if w["model"] == "vbpr" else w["I"] * world
     if world > 1 and w["model"] == "vbpr":
         for n in ("E", "Bp"):
             if rehearse:
@@ -136,9 +140,15 @@ def main():
                                   tables["F"], tables["E"], tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B,
                                   feat_dtype=w["dtype"], device=local_rank)
         eng = sharded.eng
+    elif world > 1:
+        # user-sharded BPRMF (configs[2]): user rows stay local, item rows are exchanged by all-to-all, no all-reduce
+        if args.optimizer != "sgd":
+            raise SystemExit("multi-GPU bench supports --optimizer sgd")
+        from fashionvisualexpl_recommend_amd.dist import UserShardedBPRMF
+        sharded = UserShardedBPRMF(rank, world, w["I"] * world, tables["Gu"], tables["Gi"], tables["Bi"], lr=1e-4, reg=1e-4,
+                                   max_batch=B, device=local_rank)
+        eng = sharded.eng
     else:
-        if world > 1:
-            raise SystemExit("multi-GPU bench is implemented for the VBPR workloads")
         eng = Engine(model=w["model"], num_users=w["U"], num_items=w["I"], embed_k=w["k"], embed_d=w["d"],
                      feat_dim=w["D"], feat_dtype=w["dtype"], optimizer=args.optimizer, lr=1e-4, reg=1e-4, max_batch=B,
                      device=local_rank).bind(**tables)
@@ -150,17 +160,17 @@ def main():
         from fashionvisualexpl_recommend_amd.engine import PhiloxSampler
         npu = args.pos_per_user
         # (N > 1: every GLOBAL user has pos-per-user positives inside this rank's item shard)
-        items = torch.randint(w["I"], (users_total, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
-        indptr = torch.arange(users_total + 1, device=device, dtype=torch.int64) * npu
-        pos_user = torch.arange(users_total, device=device, dtype=torch.int32).repeat_interleave(npu)
-        sampler = PhiloxSampler.from_csr(indptr, items.reshape(-1), pos_user, w["I"], seed=2024 + rank)
+        items = torch.randint(samp_items, (samp_users, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
+        indptr = torch.arange(samp_users + 1, device=device, dtype=torch.int64) * npu
+        pos_user = torch.arange(samp_users, device=device, dtype=torch.int32).repeat_interleave(npu)
+        sampler = PhiloxSampler.from_csr(indptr, items.reshape(-1), pos_user, samp_items, seed=2024 + rank)
         bufs = tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3))
         batches, nb = None, 0
     else:
         nb = min(K + W, 16)                               # distinct resident index batches, cycled
-        batches = [(torch.randint(users_total, (B,), generator=gi, device=device, dtype=torch.int32),
-                    torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32),
-                    torch.randint(w["I"], (B,), generator=gi, device=device, dtype=torch.int32)) for _ in range(nb)]
+        batches = [(torch.randint(samp_users, (B,), generator=gi, device=device, dtype=torch.int32),
+                    torch.randint(samp_items, (B,), generator=gi, device=device, dtype=torch.int32),
+                    torch.randint(samp_items, (B,), generator=gi, device=device, dtype=torch.int32)) for _ in range(nb)]
     def one_step(s):
         u, i, j = sampler.sample(B, out=bufs) if batches is None else batches[s % nb]
         if sharded is None:
@@ -236,7 +246,9 @@ def main():
             "config": {"workload": "%s: %s k=%d d=%d D=%d, %d users x %d items per GPU, %s features, B=%d per GPU, %s"
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
                                       w["dtype"], B, args.optimizer),
-                       "global_batch": B * world, "parallelism": ("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world) if world > 1 else "single",
+                       "global_batch": B * world, "parallelism": "single" if world == 1 else
+                       (("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world)
+                        if w["model"] == "vbpr" else ("user-shard x%d: all-to-all item rows, no all-reduce" % world)),
                        "sampler": ("device philox, uniform positive + rejection negative, inside the timed step (%d positives/user)"
                                    % args.pos_per_user) if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,

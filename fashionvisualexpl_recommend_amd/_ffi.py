@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbprx.so")
 ABI_VERSION = 2
 FLAG_EXPORT_USER_GRAD = 1
+FLAG_EXPORT_ITEM_GRAD = 2
 
 MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
@@ -75,6 +76,8 @@ def lib():
         "bprx_step_project": (C.c_int, [vp, vp]),
         "bprx_user_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "bprx_clear_user_grad": (C.c_int, [vp, i64, vp]),
+        "bprx_item_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "bprx_clear_item_grad": (C.c_int, [vp, i64, vp]),
         "bprx_scatter_add": (C.c_int, [vp, i32, i32, vp, vp, i64, f32, vp]),
         "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
         "bprx_eval_users": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
@@ -98,7 +101,7 @@ def lib():
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
-           "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad",
+           "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_sync_check", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]

@@ -50,8 +50,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (cfg->feat_dtype == BPRX_F_BF16 && cfg->feat_dim % 128 != 0)
       CFAIL(BPRX_E_INVALID, "bf16 features need feat_dim %% 128 == 0 (got %d)", cfg->feat_dim);
   }
-  if ((cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) && cfg->optimizer != BPRX_OPT_SGD)
-    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_USER_GRAD supports optimizer sgd only");
+  if ((cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) && cfg->optimizer != BPRX_OPT_SGD)
+    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_*_GRAD support optimizer sgd only");
+  if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->model != BPRX_MODEL_BPRMF)
+    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD is for BPRMF (VBPR keeps its items and features local)");
   hipError_t e = hipSetDevice(cfg->device);
   if (e != hipSuccess) CFAIL(BPRX_E_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
 
@@ -137,7 +139,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     }
   }
   // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
-  h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;
+  h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;   // per side: make_args
   if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
   if (h->item_mode) h->fast_rows = 0;
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
@@ -312,6 +314,22 @@ extern "C" int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream
   BPRX_HIP(h, hipMemsetAsync(h->dGu, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
   if (h->cfg.embed_d) BPRX_HIP(h, hipMemsetAsync(h->dTu, 0, (size_t)n_rows * h->cfg.embed_d * sizeof(float), s));
   BPRX_HIP(h, hipMemsetAsync(h->flagU, 0, (size_t)n_rows * sizeof(uint32_t), s));
+  return BPRX_OK;
+}
+
+extern "C" int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi) {
+  if (!h || !dGi || !dBi) return BPRX_E_INVALID;
+  *dGi = h->dGi;
+  *dBi = h->dBi;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, void *stream) {
+  if (!h || n_rows < 0 || n_rows > h->cfg.num_items) return BPRX_E_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  BPRX_HIP(h, hipMemsetAsync(h->dGi, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
+  BPRX_HIP(h, hipMemsetAsync(h->dBi, 0, (size_t)n_rows * sizeof(float), s));
+  BPRX_HIP(h, hipMemsetAsync(h->flagI, 0, (size_t)n_rows * sizeof(uint32_t), s));
   return BPRX_OK;
 }
 

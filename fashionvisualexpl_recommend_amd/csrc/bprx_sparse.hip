@@ -32,7 +32,8 @@ struct SparseArgs {
   // updated in place by that triplet's group (6 row transfers per triplet, no staging, no atomics, no apply pass)
   int32_t *cntU, *cntI;
   float *wGu, *wGi, *wBi, *wTu;   // writable aliases of the tables
-  int fast;
+  int fast;                       // any fast side on (k_apply_sgd then resets the counters)
+  int fastU, fastI;               // per side: off for rows whose gradients are exported (staging rows)
   float lr;
   const int32_t *binptr;   // item bins (item_atomics == 0): list offsets, fill cursors, records
   int32_t *bincur;
@@ -104,16 +105,15 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v) {
 // non-returning int atomics; the counters are reset to zero by k_apply_sgd.
 __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
                                                    const int32_t *__restrict__ neg, int64_t B, int U, int I,
-                                                   int32_t *__restrict__ cntU, int32_t *__restrict__ cntI) {
+                                                   int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   int u = user[b], i = pos[b], j = neg[b];             // same clamping as clamp_idx()
   u = u < 0 ? 0 : (u >= U ? U - 1 : u);
   i = i < 0 ? 0 : (i >= I ? I - 1 : i);
   j = j < 0 ? 0 : (j >= I ? I - 1 : j);
-  atomicAdd(cntU + u, 1);
-  atomicAdd(cntI + i, 1);
-  atomicAdd(cntI + j, 1);
+  if (doU) atomicAdd(cntU + u, 1);
+  if (doI) { atomicAdd(cntI + i, 1); atomicAdd(cntI + j, 1); }
 }
 
 // One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   const float g = inr ? -1.0f / (1.0f + expf(diff)) : 0.f;            // -sigmoid(-diff)
   const float reg = a.reg, r2 = 2.f * reg, lr = a.lr;
   // exclusive rows: nobody else reads or writes them in this batch, so the in-place update is batch-synchronous
-  const bool exU = a.fast && a.cntU[u] == 1;
-  const bool exI = a.fast && a.cntI[i] == 1, exJ = a.fast && a.cntI[j] == 1;      // i == j gives count 2: shared
+  const bool exU = a.fastU && a.cntU[u] == 1;
+  const bool exI = a.fastI && a.cntI[i] == 1, exJ = a.fastI && a.cntI[j] == 1;    // i == j gives count 2: shared
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
     if (!exU) a.flagU[u] = 1u;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *
   int32_t *cntp;
   if (kind == 0) { row = clamp_idx(user[b], a.U, a.errflag, 1); flag = a.flagU + row; cntp = a.cntU + row; }
   else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; cntp = a.cntI + row; }
-  if (a.fast) {                                        // rows with multiplicity 1 were finished by k_triplet_grad
+  if (kind == 0 ? a.fastU : a.fastI) {                 // rows with multiplicity 1 were finished by k_triplet_grad
     const int c1 = *cntp;
     if (lane == 0 && c1) *cntp = 0;                    // reset for the next step (every job of the row may do it)
     if (c1 == 1) return;
@@ -542,6 +542,8 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.cntU = h->cntU; a.cntI = h->cntI;
   a.wGu = h->t.Gu; a.wGi = h->t.Gi; a.wBi = h->t.Bi; a.wTu = h->t.Tu;
   a.fast = h->fast_rows;
+  a.fastU = h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD);
+  a.fastI = h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD);
   a.lr = h->cfg.lr;
   a.item_atomics = h->item_mode ? 0 : 1;
   a.binptr = h->binptr; a.bincur = h->bincnt; a.binrec = h->binrec; a.bin_shift = h->bin_shift;
@@ -628,7 +630,8 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   const int G = pick_group(a.k, a.d, vec);
   if (h->fast_rows) {
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
-    hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI);
+    hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI,
+                       a.fastU, a.fastI);
   }
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
   // W must be all-zero here: k_cast_W (backward variants >= 8) re-zeroes it while converting; other variants don't
@@ -695,7 +698,7 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     // first_kind = 1 skips the user rows (their gradients are exported to the caller: BPRX_FLAG_EXPORT_USER_GRAD)
     // item rows are finished in place by k_item_bin when that mode is on: kinds [fk, ek)
     const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
-    const int ek = h->item_mode ? 1 : 3;
+    const int ek = (h->item_mode || (h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 3;
     if (ek > fk)
       DISPATCH_G(G, vec, k_apply_sgd, grid_for((int64_t)(ek - fk) * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B,
                  lr_t, fk, ek);

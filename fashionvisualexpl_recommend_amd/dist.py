@@ -24,8 +24,9 @@ def shard_size(total, world):
 
 
 class UserRowExchange:
-    """Routing of user rows between the ranks that use them and the ranks that own them.  Pure tensor + collective
-    logic (no kernels): works on CPU tensors with gloo (tests) and on device tensors with nccl."""
+    """Routing of table rows (user rows for item-sharded VBPR, item rows for user-sharded BPRMF) between the ranks that
+    use them and the ranks that own them.  Pure tensor + collective logic (no kernels): works on CPU tensors with gloo
+    (tests) and on device tensors with nccl."""
 
     def __init__(self, rank, world, users_total, group=None):
         self.rank, self.world, self.group = rank, world, group
@@ -134,4 +135,58 @@ class ItemShardedVBPR:
         self.eng.clear_user_grad(B)
         self._scatter_add(self.Gu_shard, ridx, g_back.contiguous(), -self.lr)
         self._scatter_add(self.Tu_shard, ridx, t_back.contiguous(), -self.lr)
+        return loss
+
+
+RowExchange = UserRowExchange      # the routing is the same whichever table is the remote one
+
+
+class UserShardedBPRMF:
+    """Per-rank driver of user-sharded BPRMF (BASELINE.json configs[2]): rank r owns the Gu rows of its users and samples
+    only its own users' positives, so user rows never move; Gi/Bi are range-partitioned by item id and the rows of the
+    batch's positive and negative items are fetched from / their gradients returned to the item owners by all-to-all
+    (staging row b = positive item of triplet b, row B+b = its negative item; BPRX_FLAG_EXPORT_ITEM_GRAD).
+    No dense parameter, hence no all-reduce at all.  The global step equals the single-GPU batch-synchronous step on the
+    concatenation of all ranks' batches.  sgd only."""
+
+    def __init__(self, rank, world, items_total, Gu_shard, Gi_shard, Bi_shard, lr, reg, max_batch, group=None, device=None):
+        from .engine import Engine, scatter_add
+        self._scatter_add = scatter_add
+        self.rank, self.world, self.group, self.lr = rank, world, group, lr
+        self.x = RowExchange(rank, world, items_total, group)
+        k = Gu_shard.shape[1]
+        self.eng = Engine(model="bprmf", num_users=Gu_shard.shape[0], num_items=2 * max_batch, embed_k=k, optimizer="sgd",
+                          lr=lr, reg=reg, max_batch=max_batch, device=device, export_item_grad=True)
+        dev = self.eng.device
+        self.GiBi_shard = torch.cat([Gi_shard.to(dev).float(), Bi_shard.to(dev).float().reshape(-1, 1)], dim=1).contiguous()
+        self.stage_Gi = torch.zeros((2 * max_batch, k), dtype=torch.float32, device=dev)
+        self.stage_Bi = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
+        self.eng.bind(Gu=Gu_shard, Gi=self.stage_Gi, Bi=self.stage_Bi)
+        self.iota = torch.arange(2 * max_batch, dtype=torch.int32, device=dev)
+        self.k = k
+
+    @property
+    def Gi_shard(self):
+        return self.GiBi_shard[:, :self.k]
+
+    @property
+    def Bi_shard(self):
+        return self.GiBi_shard[:, self.k]
+
+    def step(self, u_local, i_global, j_global, want_loss=False):
+        B, k = u_local.numel(), self.k
+        items = torch.cat([i_global, j_global])                                   # 2B requested rows
+        order, sc, rc, ridx = self.x.plan(items)
+        (rows,) = self.x.fetch([self.GiBi_shard], ridx, sc, rc)                   # [2B, k+1] in owner-sorted order
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)             # back to batch order
+        rows = rows.index_select(0, inv)
+        self.stage_Gi[:2 * B].copy_(rows[:, :k])
+        self.stage_Bi[:2 * B].copy_(rows[:, k])
+        loss = self.eng.step(u_local, self.iota[:B], self.iota[B:2 * B], want_loss=want_loss)
+        dG, dB = self.eng.item_grad()
+        g = torch.cat([dG[:2 * B], dB[:2 * B].reshape(-1, 1)], dim=1).index_select(0, order)   # owner-sorted order again
+        (back,) = self.x.give_back([g], sc, rc)
+        self.eng.clear_item_grad(2 * B)
+        self._scatter_add(self.GiBi_shard, ridx, back.contiguous(), -self.lr)
         return loss

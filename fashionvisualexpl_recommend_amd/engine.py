@@ -34,7 +34,7 @@ def as_index(x, device):
 class Engine:
     def __init__(self, model, num_users, num_items, embed_k, embed_d=0, feat_dim=0, feat_dtype="fp32",
                  optimizer="adam_tf23", lr=1e-3, reg=0.0, max_batch=256, device=None,
-                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False):
+                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False, export_item_grad=False):
         if not torch.cuda.is_available():
             raise RuntimeError("fashionvisualexpl_recommend_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _ffi.lib()
@@ -46,7 +46,9 @@ class Engine:
         self.max_batch = int(max_batch)
         cfg = _ffi.Config(_ffi.ABI_VERSION, _ffi.MODEL[model], self.U, self.I, self.k, self.d, self.D,
                           _ffi.FEAT_DTYPE[feat_dtype], _ffi.OPTIMIZER[optimizer], self.device.index, self.max_batch,
-                          lr, reg, beta1, beta2, epsilon, _ffi.FLAG_EXPORT_USER_GRAD if export_user_grad else 0)
+                          lr, reg, beta1, beta2, epsilon,
+                          (_ffi.FLAG_EXPORT_USER_GRAD if export_user_grad else 0) |
+                          (_ffi.FLAG_EXPORT_ITEM_GRAD if export_item_grad else 0))
         h = C.c_void_p()
         _ffi.check(None, self.lib.bprx_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -148,6 +150,18 @@ class Engine:
             t = _DevView(b.value, self.U * self.d, self.device).tensor.view(self.U, self.d) if self.d else None
             self._ugrad = (g, t)
         return self._ugrad
+
+    def item_grad(self):
+        """Zero-copy views [I,k], [I] of the staging tables that hold the exported item-row gradients."""
+        if getattr(self, "_igrad", None) is None:
+            a, b = C.c_void_p(), C.c_void_p()
+            _ffi.check(self.h, self.lib.bprx_item_grad(self.h, C.byref(a), C.byref(b)))
+            self._igrad = (_DevView(a.value, self.I * self.k, self.device).tensor.view(self.I, self.k),
+                           _DevView(b.value, self.I, self.device).tensor)
+        return self._igrad
+
+    def clear_item_grad(self, n_rows):
+        _ffi.check(self.h, self.lib.bprx_clear_item_grad(self.h, int(n_rows), _stream()))
 
     def clear_user_grad(self, n_rows):
         _ffi.check(self.h, self.lib.bprx_clear_user_grad(self.h, int(n_rows), _stream()))

@@ -76,7 +76,10 @@ typedef struct {
    their owner ranks (row b = the user row of triplet b); the step leaves their summed gradients in the buffers of
    bprx_user_grad() instead of applying them, and the caller routes those rows back to the owners
    (bprx_scatter_add with scale = -lr) and clears them with bprx_clear_user_grad(). */
-enum { BPRX_FLAG_EXPORT_USER_GRAD = 1 };
+enum { BPRX_FLAG_EXPORT_USER_GRAD = 1, BPRX_FLAG_EXPORT_ITEM_GRAD = 2 };
+/* BPRX_FLAG_EXPORT_ITEM_GRAD (user-sharded multi-GPU BPRMF, sgd only): the mirror image -- the bound Gi/Bi are per-step
+   STAGING rows fetched from the item owners (row b = the positive item row of triplet b, row B+b its negative item row);
+   their gradients are left in the buffers of bprx_item_grad() and cleared with bprx_clear_item_grad(). */
 
 /* Device pointers to the model state.  Unused entries (BPRMF: Tu,F,E,Bp; sgd: every m_/v_) are NULL. */
 typedef struct {
@@ -129,6 +132,8 @@ BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
 BPRX_API int bprx_step_project(bprx_handle *h, void *stream);
 BPRX_API int bprx_user_grad(bprx_handle *h, float **dGu, float **dTu);
 BPRX_API int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream);
+BPRX_API int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi);
+BPRX_API int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, void *stream);
 BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,
                               int64_t n, float scale, void *stream);
 

@@ -77,3 +77,51 @@ def _worker(rank, world, port, dtype):
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_item_sharded_vbpr_two_ranks_match_oracle(dtype):
     mp.spawn(_worker, args=(2, _free_port(), dtype), nprocs=2, join=True)
+
+
+def _worker_bprmf(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fashionvisualexpl_recommend_amd import synth
+        from fashionvisualexpl_recommend_amd.dist import UserShardedBPRMF, shard_size
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        U, I, k, B, lr, reg = 60, 75, 16, 128, 0.05, 1e-3
+        ush, ish = U // world, shard_size(I, world)
+        rs = np.random.RandomState(2)
+        t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k),
+                 Bi=(rs.standard_normal(I) * 0.01).astype(np.float32))
+        us, it = slice(rank * ush, (rank + 1) * ush), slice(rank * ish, min(I, (rank + 1) * ish))
+        c = lambda a: torch.as_tensor(a.copy())
+        m = UserShardedBPRMF(rank, world, I, c(t["Gu"][us]), c(t["Gi"][it]), c(t["Bi"][it]), lr, reg, max_batch=B, device=0)
+        o = orc.OracleModel(**t)
+        for step in range(3):
+            batches = []
+            for r in range(world):
+                br = np.random.RandomState(200 + step * world + r)
+                nb = B - 17 * r
+                batches.append((br.randint(ush, size=nb).astype(np.int32), br.randint(I, size=nb).astype(np.int32),
+                                br.randint(I, size=nb).astype(np.int32)))
+            u, i, j = batches[rank]
+            i[:4] = 7                                      # the same remote/local item several times, also as negative
+            j[4:6] = 7
+            dev = lambda a: torch.as_tensor(a, device="cuda")
+            m.step(dev(u), dev(i), dev(j))
+            for r, b in enumerate(batches):
+                if r != rank:
+                    b[1][:4] = 7
+                    b[2][4:6] = 7
+            o.step(np.concatenate([b[0] + r * ush for r, b in enumerate(batches)]), np.concatenate([b[1] for b in batches]),
+                   np.concatenate([b[2] for b in batches]), "sgd", lr, reg)
+        m.eng.sync_check()
+        chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
+        chk(m.eng.t["Gu"], o.Gu[us], "Gu shard")
+        chk(m.Gi_shard, o.Gi[it], "Gi shard")
+        chk(m.Bi_shard, o.Bi[it], "Bi shard")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_user_sharded_bprmf_two_ranks_match_oracle():
+    mp.spawn(_worker_bprmf, args=(2, _free_port()), nprocs=2, join=True)
