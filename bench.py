@@ -41,8 +41,10 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam_tf23"])
-    ap.add_argument("--sampler", default="philox", choices=["philox", "pregen"],
-                    help="philox: device sampler inside the timed step; pregen: resident pre-generated index batches")
+    ap.add_argument("--sampler", default="philox", choices=["philox", "epoch", "pregen"],
+                    help="philox: device sampler, i.i.d. uniform interactions, inside the timed step; epoch: device "
+                         "epoch-walk sampler (the reference's visiting order: user-grouped batches); pregen: resident "
+                         "pre-generated index batches")
     ap.add_argument("--pos-per-user", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
@@ -155,15 +157,16 @@ def main():
 
     gi = torch.Generator(device=device)
     gi.manual_seed(99 + rank)
-    if args.sampler == "philox":
+    if args.sampler in ("philox", "epoch"):
         # synthetic training interactions resident in HBM: pos-per-user uniform items per user, CSR sorted per user
-        from fashionvisualexpl_recommend_amd.engine import PhiloxSampler
+        from fashionvisualexpl_recommend_amd.engine import EpochWalkSampler, PhiloxSampler
         npu = args.pos_per_user
         # (N > 1: every GLOBAL user has pos-per-user positives inside this rank's item shard)
         items = torch.randint(samp_items, (samp_users, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
         indptr = torch.arange(samp_users + 1, device=device, dtype=torch.int64) * npu
         pos_user = torch.arange(samp_users, device=device, dtype=torch.int32).repeat_interleave(npu)
-        sampler = PhiloxSampler.from_csr(indptr, items.reshape(-1), pos_user, samp_items, seed=2024 + rank)
+        cls = EpochWalkSampler if args.sampler == "epoch" else PhiloxSampler
+        sampler = cls.from_csr(indptr, items.reshape(-1), pos_user, samp_items, seed=2024 + rank)
         bufs = tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3))
         batches, nb = None, 0
     else:
@@ -249,8 +252,10 @@ def main():
                        "global_batch": B * world, "parallelism": "single" if world == 1 else
                        (("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world)
                         if w["model"] == "vbpr" else ("user-shard x%d: all-to-all item rows, no all-reduce" % world)),
-                       "sampler": ("device philox, uniform positive + rejection negative, inside the timed step (%d positives/user)"
-                                   % args.pos_per_user) if batches is None else "pre-generated uniform (u,i,j), resident"},
+                       "sampler": (("device philox, uniform positive + rejection negative" if args.sampler == "philox" else
+                                    "device epoch walk (every positive once per epoch, user-grouped) + philox negative")
+                                   + ", inside the timed step (%d positives/user)" % args.pos_per_user)
+                       if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,
             "step_roofline": {"bytes_per_triplet": per_trip, "achieved": value * per_trip / 1e9 / world,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value * per_trip / 1e9 / world / HBM_PEAK_GBS},

@@ -54,7 +54,57 @@ __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict
   u[b] = uu; i[b] = items[p]; j[b] = jj;
 }
 
+// Epoch-walk mode (the reference's order, dataset.py:93-107, as a stateless stream): within epoch e the users come in the
+// order perm[0..U) and every positive of a user is emitted once, consecutively; stream position n (0 <= n < N) of the
+// epoch maps to the user a with epoch_ptr[a] <= n < epoch_ptr[a+1] (binary search) and to that user's positive number
+// n - epoch_ptr[a].  The negative is the Philox rejection draw keyed by (seed; n, epoch).  Batches are user-grouped like
+// the reference's, every interaction is visited exactly once per epoch.
+__global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict__ indptr, const int32_t *__restrict__ items,
+                                                      const int32_t *__restrict__ perm, const int64_t *__restrict__ epoch_ptr,
+                                                      int U, uint32_t I, uint32_t k0, uint32_t k1, uint32_t epoch,
+                                                      long long first, long long B, int32_t *__restrict__ u,
+                                                      int32_t *__restrict__ i, int32_t *__restrict__ j) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const long long n = first + b;
+  int lo = 0, hi = U;                                   // largest a with epoch_ptr[a] <= n
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (epoch_ptr[mid] <= n) lo = mid; else hi = mid;
+  }
+  const int32_t uu = perm[lo];
+  const long long l0 = indptr[uu], len = indptr[uu + 1] - l0;
+  const int32_t *lst = items + l0;
+  uint32_t r[4];
+  int32_t jj = 0;
+  for (uint32_t a = 0; a < 1024u; ++a) {
+    philox4x32_10((uint32_t)n, (uint32_t)((unsigned long long)n >> 32), a, epoch, k0, k1, r);
+    jj = (int32_t)__umulhi(r[2], I);
+    long long l = 0, h = len;
+    while (l < h) {
+      const long long mid = (l + h) >> 1;
+      if (lst[mid] < jj) l = mid + 1; else h = mid;
+    }
+    if (!(l < len && lst[l] == jj)) break;
+  }
+  u[b] = uu; i[b] = lst[n - epoch_ptr[lo]]; j[b] = jj;
+}
+
 }  // namespace
+
+extern "C" int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
+                                 const int64_t *epoch_ptr, int32_t num_users, int32_t num_items, uint64_t seed,
+                                 uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
+                                 void *stream) {
+  if (!indptr || !items_sorted || !perm || !epoch_ptr || !user || !pos || !neg || num_users <= 0 || num_items <= 0 ||
+      B < 0 || first < 0)
+    return BPRX_E_INVALID;
+  if (B == 0) return BPRX_OK;
+  hipLaunchKernelGGL(k_sample_epoch, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
+                     items_sorted, perm, epoch_ptr, num_users, (uint32_t)num_items, (uint32_t)seed, (uint32_t)(seed >> 32),
+                     epoch, (long long)first, (long long)B, user, pos, neg);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}
 
 extern "C" int bprx_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user,
                                   int64_t num_pos, int32_t num_items, uint64_t seed, uint64_t first, int64_t B,

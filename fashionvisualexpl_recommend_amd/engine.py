@@ -253,6 +253,41 @@ class PhiloxSampler:
         return u, i, j
 
 
+class EpochWalkSampler(PhiloxSampler):
+    """bprx_sample_epoch: the reference's visiting order as a device stream -- per epoch a fresh permutation of the users
+    (host NumPy RandomState(seed + epoch), 4 B per user uploaded once per epoch), every positive of every user exactly
+    once, consecutively; negatives by Philox rejection.  Batches are user-grouped like the reference's."""
+
+    def _start_epoch(self, epoch):
+        U = self.indptr.numel() - 1
+        perm = np.random.RandomState((self.seed + epoch) % (2 ** 32)).permutation(U).astype(np.int32)
+        self.perm = torch.as_tensor(perm, device=self.device)
+        lens = (self.indptr[1:] - self.indptr[:-1]).index_select(0, self.perm.long())
+        self.epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens, 0, out=self.epoch_ptr[1:])
+        self.epoch, self.pos_in_epoch = epoch, 0
+
+    def sample(self, B, first=None, out=None):
+        if first is not None:
+            raise ValueError("the epoch walk is a sequential stream")
+        if getattr(self, "perm", None) is None:
+            self._start_epoch(0)
+        u, i, j = out if out is not None else tuple(torch.empty(B, dtype=torch.int32, device=self.device) for _ in range(3))
+        done = 0
+        while done < B:
+            n = min(B - done, self.num_pos - self.pos_in_epoch)
+            rc = self.lib.bprx_sample_epoch(_ptr(self.indptr), _ptr(self.items), _ptr(self.perm), _ptr(self.epoch_ptr),
+                                            self.indptr.numel() - 1, self.num_items, self.seed, self.epoch,
+                                            self.pos_in_epoch, n, _ptr(u[done:]), _ptr(i[done:]), _ptr(j[done:]), _stream())
+            if rc < 0:
+                raise _ffi.BprxError(rc, "bprx_sample_epoch failed")
+            done += n
+            self.pos_in_epoch += n
+            if self.pos_in_epoch >= self.num_pos:
+                self._start_epoch(self.epoch + 1)
+        return u, i, j
+
+
 class HostSampler:
     """bprx_sampler_*: the reference-compatible host index stream (dataset.py:83-114)."""
 

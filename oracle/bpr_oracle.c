@@ -551,3 +551,29 @@ void orc_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const
     u[b] = uu; i[b] = items_sorted[p]; j[b] = jj;
   }
 }
+
+/* CPU twin of the epoch-walk device sampler (bprx_sample_epoch): position n of epoch `epoch` -> user perm[a] with
+   epoch_ptr[a] <= n < epoch_ptr[a+1], its positive number n - epoch_ptr[a]; negative = Philox rejection keyed by
+   (seed; n, epoch). */
+void orc_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm, const int64_t *epoch_ptr,
+                      int32_t U, int32_t I, uint64_t seed, uint32_t epoch, int64_t first, int64_t B,
+                      int32_t *u, int32_t *i, int32_t *j) {
+  for (int64_t b = 0; b < B; b++) {
+    int64_t n = first + b;
+    int32_t lo = 0, hi = U;
+    while (hi - lo > 1) { int32_t mid = (lo + hi) >> 1; if (epoch_ptr[mid] <= n) lo = mid; else hi = mid; }
+    int32_t uu = perm[lo];
+    const int32_t *lst = items_sorted + indptr[uu];
+    int64_t len = indptr[uu + 1] - indptr[uu];
+    uint32_t r[4];
+    int32_t jj = 0;
+    for (uint32_t a = 0; a < 1024; a++) {
+      philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), a, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      jj = (int32_t)(((uint64_t)r[2] * (uint64_t)(uint32_t)I) >> 32);
+      int64_t l = 0, h = len;
+      while (l < h) { int64_t mid = (l + h) >> 1; if (lst[mid] < jj) l = mid + 1; else h = mid; }
+      if (!(l < len && lst[l] == jj)) break;
+    }
+    u[b] = uu; i[b] = lst[n - epoch_ptr[lo]]; j[b] = jj;
+  }
+}

@@ -57,6 +57,8 @@ def lib():
                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_sample_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint64,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sample_epoch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64,
+                                       C.c_uint32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bf16_round.restype = C.c_float
         L.orc_bf16_round.argtypes = [C.c_float]
         L.orc_num_threads.restype = C.c_int
@@ -104,6 +106,18 @@ def sample_philox(train_lists, num_items, seed, first, B):
     indptr, items, pos_user = interactions_csr(train_lists)
     u = np.empty(B, np.int32); i = np.empty(B, np.int32); j = np.empty(B, np.int32)
     lib().orc_sample_philox(_p(indptr), _p(items), _p(pos_user), len(items), num_items, seed, first, B, _p(u), _p(i), _p(j))
+    return u, i, j
+
+
+def sample_epoch(train_lists, num_items, seed, epoch, first, B):
+    """Twin of EpochWalkSampler for one epoch: same host permutation RandomState(seed + epoch), same prefix sums."""
+    indptr, items, _ = interactions_csr(train_lists)
+    U = len(train_lists)
+    perm = np.random.RandomState((seed + epoch) % (2 ** 32)).permutation(U).astype(np.int32)
+    eptr = np.zeros(U + 1, np.int64)
+    eptr[1:] = np.cumsum(np.diff(indptr)[perm])
+    u = np.empty(B, np.int32); i = np.empty(B, np.int32); j = np.empty(B, np.int32)
+    lib().orc_sample_epoch(_p(indptr), _p(items), _p(perm), _p(eptr), U, num_items, seed, epoch, first, B, _p(u), _p(i), _p(j))
     return u, i, j
 
 

@@ -253,3 +253,31 @@ def test_device_eval_multi_item_lists_match_oracle():
     r = r[r[:, 0] >= 0]
     for c, key in enumerate(("hr_t", "p_t", "r_t", "auc_t", "ndcg_t")):
         assert r[:, c].mean() == pytest.approx(want[key], abs=1e-12), key
+
+
+def test_epoch_walk_sampler_bit_exact_and_grouped_step():
+    """bprx_sample_epoch vs its CPU twin (bit-exact, across an epoch boundary), and a train step on its user-grouped
+    batches (exercises the wave-level combination of user-row gradients) vs the oracle."""
+    from fashionvisualexpl_recommend_amd.engine import EpochWalkSampler
+    U, I, k, B = 90, 150, 64, 512
+    tr, _, _ = synth.make_interactions(U, I, per_user=22, seed=8)
+    tr[4] = []                                             # a user without positives is skipped
+    N = sum(len(l) for l in tr)
+    s = EpochWalkSampler(tr, I, seed=31)
+    got = [tuple(t.cpu().numpy() for t in s.sample(B)) for _ in range(5)]           # 2560 > N = 1780: crosses an epoch
+    u = np.concatenate([g[0] for g in got]); i = np.concatenate([g[1] for g in got]); j = np.concatenate([g[2] for g in got])
+    w0 = orc.sample_epoch(tr, I, 31, 0, 0, N)
+    w1 = orc.sample_epoch(tr, I, 31, 1, 0, 5 * B - N)
+    assert np.array_equal(u, np.concatenate([w0[0], w1[0]])) and np.array_equal(i, np.concatenate([w0[1], w1[1]]))
+    assert np.array_equal(j, np.concatenate([w0[2], w1[2]]))
+    assert sorted(zip(u[:N].tolist(), i[:N].tolist())) == sorted((a, b) for a, l in enumerate(tr) for b in l)
+    t = _tables(U, I, k, seed=12)
+    e = _engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=0.05, reg=1e-3, max_batch=B).bind(**t)
+    o = orc.OracleModel(**t)
+    for step in range(3):
+        ub, ib, jb = got[step]
+        loss = e.step(_dev(ub), _dev(ib), _dev(jb)).item()
+        assert loss == pytest.approx(o.step(ub, ib, jb, "sgd", 0.05, 1e-3), rel=2e-5)
+        for n in ("Gu", "Gi", "Bi"):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), 2e-5, 2e-6, "%s step %d" % (n, step))
+    e.sync_check()
