@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->bincnt, h->binptr, h->binrec, h->cntU, h->cntI};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->cntU, h->cntI};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -109,29 +109,19 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     return BPRX_E_NOMEM;
   }
   {
-    // item-side gradients through LDS bins (k_item_bin) when the item table fits a few rounds of workgroups;
-    // otherwise (very wide rows x very many items) the global-atomic staging path is kept.
-    const int PSv = vb ? h->PS : 4;
-    h->bin_rs = (int)k + PSv;
-    const int row_bytes = h->bin_rs * 4 + 8;
-    int shift = 0;
-    while ((2 << shift) * row_bytes <= 38 * 1024 && (2 << shift) <= 1024) ++shift;    // R = 2^shift rows, <= 38 KB of LDS
-    h->bin_shift = shift;
-    const int R = 1 << shift;
-    h->bin_count = (int)((I + R - 1) / R);
-    h->bin_lds = R * row_bytes;
-    // Measured on C2 (profiles/r01_sweeps.md): the bin path is CORRECT but slower than the atomic staging path it was
-    // meant to replace (bin_index 18 + appends +43 + k_item_bin 139 us vs 109 + 36 us): contended returning int atomics
-    // for the appends and latency-bound per-bin record walks.  It stays off unless BPRX_ITEM_MODE=1 (experiments).
-    h->item_mode = 0;
-    if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = atoi(e) ? (R * row_bytes <= 150 * 1024) : 0;
-    if (h->item_mode && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // needs Wb
+    // Item-side gradients through per-item occurrence segments (k_item_seg) instead of global float atomics: the
+    // default whenever the row widths fit the 16-B-per-lane layout and the item rows are not staging rows of a sharded
+    // run.  BPRX_ITEM_MODE=0 forces the atomic staging path (A/B measurements: profiles/r01_sweeps.md).
+    const bool fits = k % 4 == 0 && d % 4 == 0 && k <= 256 && d <= 256;
+    h->item_mode = (fits && !(cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 0;
+    if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = h->item_mode && atoi(e);
+    if (h->item_mode && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
     if (h->item_mode) {
-      bool ok2 = dalloc_zero(&h->bincnt, (size_t)h->bin_count) == hipSuccess &&
-                 dalloc_zero(&h->binptr, (size_t)h->bin_count + 1) == hipSuccess &&
-                 dalloc_zero((int4 **)&h->binrec, (size_t)2 * MB) == hipSuccess;
+      bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_ptr, I) == hipSuccess &&
+                 dalloc_zero(&h->seg_cursor, (size_t)1) == hipSuccess &&
+                 dalloc_zero((int2 **)&h->seg_ent, (size_t)2 * MB) == hipSuccess;
       if (!ok2) {
-        snprintf(g_create_err, sizeof(g_create_err), "bin scratch allocation failed");
+        snprintf(g_create_err, sizeof(g_create_err), "segment scratch allocation failed");
         free_scratch(h);
         delete h;
         return BPRX_E_NOMEM;
@@ -141,7 +131,6 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
   h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;   // per side: make_args
   if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
-  if (h->item_mode) h->fast_rows = 0;
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -264,9 +253,8 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
   }
   h->proj_fresh = false;
-  if ((rc = bprx_launch_bin_index(h, pos, neg, B, s))) return rc;                       // bin lists of the 2B occurrences
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
-  if ((rc = bprx_launch_item_bin(h, h->cfg.lr, s))) return rc;                          // item rows + W, no float atomics
+  if ((rc = bprx_launch_item_seg(h, pos, neg, B, h->cfg.lr, s))) return rc;             // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
   // projection -- with VBPR it runs on the side stream beside it
   float lr_t = h->cfg.lr;

@@ -39,10 +39,12 @@ struct bprx_handle {
   int SK;
   int fast_rows;                  // sgd: rows used by exactly one triplet of the batch are updated in place
   int32_t *cntU, *cntI;           // [U], [I] row multiplicities of the current batch (all-zero between steps)
-  int item_mode;                  // 1: item-side gradients by k_item_bin (LDS bins), 0: global atomics + apply
-  int bin_shift, bin_rs, bin_count, bin_lds;   // bin = item >> bin_shift; LDS row stride (floats); #bins; LDS bytes
-  int32_t *bincnt, *binptr;       // [bin_count] counters / cursors, [bin_count + 1] list offsets
-  void *binrec;                   // [2 * max_batch] 16-byte records {user, +-g, item, role}
+  int item_mode;                  // 1: item-side gradients by per-item occurrence segments (k_item_seg), 0: global
+                                  //    float atomics into the staging tables + claim-apply
+  int32_t *seg_rank;              // [2 * max_batch] rank of occurrence (role*B + b) among its item's occurrences
+  int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent (valid for items of the current batch)
+  int32_t *seg_cursor;            // [1] bump allocator of segments
+  void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
   // side stream: the sparse optimizer pass (k_apply_sgd / adam sweeps: factor tables only) runs beside the backward
@@ -98,8 +100,7 @@ int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_
                       int p_by_pair, float *x, hipStream_t s);
 int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
                              hipStream_t s);
-int bprx_launch_bin_index(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s);
-int bprx_launch_item_bin(bprx_handle *h, float lr_t, hipStream_t s);
+int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, float lr_t, hipStream_t s);
 int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
                       float lr_t, hipStream_t s);
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s);

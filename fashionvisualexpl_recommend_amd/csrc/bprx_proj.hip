@@ -520,7 +520,7 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
     int rps3 = (I + h->SK - 1) / h->SK;
     rps3 = (rps3 + bt3 - 1) / bt3 * bt3;
     const size_t n4 = (size_t)I * h->PS / 4;
-    if (!h->item_mode)   // k_item_bin has already written Wb (bf16) itself
+    if (!h->item_mode)   // k_item_seg has already written Wb (bf16) itself
       hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
     dim3 g3(D / 128, h->SK);
     if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);

@@ -27,7 +27,7 @@ struct SparseArgs {
   int32_t *errflag;
   int U, I, k, d, PS;
   float reg;
-  int item_atomics;   // 1: item-side gradients by global atomics (staging tables); 0: left to k_item_bin
+  int item_atomics;   // 1: item-side gradients by global atomics (staging tables); 0: occurrence segments + k_item_seg
   // exclusive-row fast path (sgd): multiplicity of every row in the batch; rows used by exactly one triplet are
   // updated in place by that triplet's group (6 row transfers per triplet, no staging, no atomics, no apply pass)
   int32_t *cntU, *cntI;
@@ -35,11 +35,13 @@ struct SparseArgs {
   int fast;                       // any fast side on (k_apply_sgd then resets the counters)
   int fastU, fastI;               // per side: off for rows whose gradients are exported (staging rows)
   float lr;
-  const int32_t *binptr;   // item bins (item_atomics == 0): list offsets, fill cursors, records
-  int32_t *bincur;
-  void *binrec;
-  int bin_shift;
+  // occurrence segments (item_atomics == 0)
+  const int32_t *seg_rank;   // [2B] rank of occurrence (role*B + b) within its item
+  const int32_t *seg_ptr;    // [I]  first entry of the item's segment
+  int2 *seg_ent;             // [2B] {user | role << 31, g_b}
 };
+
+constexpr int SEG_CAP = 64;   // occurrences of one item beyond this rank take the global-atomic path (hot items)
 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
@@ -101,19 +103,56 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v) {
   atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
 }
 
+__device__ __forceinline__ int clamp_quiet(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }   // as clamp_idx()
+
 // Multiplicity of every user / item row in the batch (an item counts in both roles).  One thread per triplet, three
-// non-returning int atomics; the counters are reset to zero by k_apply_sgd.
+// int atomics (non-returning; returning on the item side when `rank` is wanted: the value returned is the rank of the
+// occurrence among its item's occurrences).  The counters are reset by k_apply_sgd (users) / k_item_seg (items).
 __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
                                                    const int32_t *__restrict__ neg, int64_t B, int U, int I,
-                                                   int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI) {
+                                                   int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI,
+                                                   int32_t *__restrict__ rank) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
-  int u = user[b], i = pos[b], j = neg[b];             // same clamping as clamp_idx()
-  u = u < 0 ? 0 : (u >= U ? U - 1 : u);
-  i = i < 0 ? 0 : (i >= I ? I - 1 : i);
-  j = j < 0 ? 0 : (j >= I ? I - 1 : j);
+  const int u = clamp_quiet(user[b], U), i = clamp_quiet(pos[b], I), j = clamp_quiet(neg[b], I);
   if (doU) atomicAdd(cntU + u, 1);
-  if (doI) { atomicAdd(cntI + i, 1); atomicAdd(cntI + j, 1); }
+  if (rank) {
+    rank[b] = atomicAdd(cntI + i, 1);
+    rank[B + b] = atomicAdd(cntI + j, 1);
+  } else if (doI) { atomicAdd(cntI + i, 1); atomicAdd(cntI + j, 1); }
+}
+
+// Segment allocation: the rank-0 occurrence of every item of the batch reserves cnt[item] entries.  One thread per
+// occurrence; the reservations of a 1024-thread workgroup are prefix-summed (shuffles + LDS) and taken with ONE atomic
+// on the cursor (same-address returning atomics cost ~15 ns each: one per wave measured 32 us for 2K waves).
+__global__ __launch_bounds__(1024) void k_seg_alloc(const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
+                                                    int64_t B, int I, const int32_t *__restrict__ rank,
+                                                    const int32_t *__restrict__ cntI, int32_t *__restrict__ seg_ptr,
+                                                    int32_t *__restrict__ cursor) {
+  __shared__ int wsum[16];
+  __shared__ int wbase;
+  const int64_t job = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int item = 0, c = 0;
+  if (job < 2 * B) {
+    item = clamp_quiet(job < B ? pos[job] : neg[job - B], I);
+    if (rank[job] == 0) c = cntI[item];
+  }
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int q = 0; q < 16; ++q) { const int v = wsum[q]; wsum[q] = t; t += v; }
+    wbase = t ? atomicAdd(cursor, t) : 0;
+  }
+  __syncthreads();
+  if (c) seg_ptr[item] = wbase + wsum[w] + incl - c;
 }
 
 // One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
@@ -182,25 +221,26 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   // exclusive rows: nobody else reads or writes them in this batch, so the in-place update is batch-synchronous
   const bool exU = a.fastU && a.cntU[u] == 1;
   const bool exI = a.fastI && a.cntI[i] == 1, exJ = a.fastI && a.cntI[j] == 1;    // i == j gives count 2: shared
+  // item side: global atomics, or (segments) one 8-byte entry per occurrence; occurrences of rank >= SEG_CAP of a hot
+  // item stay on the atomic path and are folded in by k_item_seg
+  bool iaI = true, iaJ = true;
+  int rkI = 0, rkJ = 0;
+  if (!a.item_atomics) {
+    rkI = a.seg_rank[b]; rkJ = a.seg_rank[B + b];
+    iaI = rkI >= SEG_CAP; iaJ = rkJ >= SEG_CAP;
+  }
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
     if (!exU) a.flagU[u] = 1u;
-    if (a.item_atomics) {
+    if (iaI) {
       if (exI) a.wBi[i] = bi - lr * (g + r2 * bi);
       else { atomicAdd(a.dBi + i, g + r2 * bi); a.flagI[i] = 1u; }
+    } else a.seg_ent[a.seg_ptr[i] + rkI] = make_int2(u, __float_as_int(g));
+    if (iaJ) {
       if (exJ) a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj);
       else { atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj); a.flagI[j] = 1u; }
-    } else {                                           // one record per occurrence into its bin's list
-      struct Rec { int32_t u; float sg; int32_t item; int32_t pad; };
-      Rec *recs = reinterpret_cast<Rec *>(a.binrec);
-      const int bi_ = i >> a.bin_shift, bj_ = j >> a.bin_shift;
-      const int si = a.binptr[bi_] + atomicAdd(a.bincur + bi_, 1);
-      recs[si] = Rec{u, g, i, 0};
-      const int sj = a.binptr[bj_] + atomicAdd(a.bincur + bj_, 1);
-      recs[sj] = Rec{u, -g, j, 1};
-    }
+    } else a.seg_ent[a.seg_ptr[j] + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
   }
-  const bool ia = a.item_atomics != 0;
   // ---- backward: per-occurrence gradients from the same pre-update rows (L1/L2 hits) ----
   // Lane l of the group owns elements l, l+G, ...: every atomic wave-instruction then adds G CONTIGUOUS dwords per
   // row (full 64-B memory-side atomic requests).  The float4 layout of the forward pass would scatter each
@@ -225,9 +265,12 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
       if (lead) atomicAdd(au + c, du);
     } else atomicAdd(au + c, du);
-    if (ia) {
-      const float di = g * p + r2 * q, dj = -g * p + r2 * r;
+    if (iaI) {
+      const float di = g * p + r2 * q;
       if (exI) pi[c] = q - lr * di; else atomicAdd(ai + c, di);
+    }
+    if (iaJ) {
+      const float dj = -g * p + r2 * r;
       if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj);
     }
   }
@@ -246,10 +289,9 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
           if (lead) atomicAdd(at + c, dt);
         } else atomicAdd(at + c, dt);
       }
-      if (ia) {                                          // W is all-zero before the step: a sole contributor stores
-        if (exI) wi[c] = g * p; else atomicAdd(wi + c, g * p);
-        if (exJ) wj[c] = -g * p; else atomicAdd(wj + c, -g * p);
-      }
+      // W is all-zero before the step: a sole contributor stores
+      if (iaI) { if (exI) wi[c] = g * p; else atomicAdd(wi + c, g * p); }
+      if (iaJ) { if (exJ) wj[c] = -g * p; else atomicAdd(wj + c, -g * p); }
     }
   }
 }
@@ -427,126 +469,121 @@ __device__ __forceinline__ uint16_t f2bf_s(float x) {   // round-to-nearest-even
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Item-side gradients without global float atomics ("item bins").
-//   bin = item >> bin_shift: a workgroup of k_item_bin owns the R = 2^bin_shift items of one bin.
-//   k_bin_count    histogram of the batch's 2B item occurrences over the bins (LDS histogram per workgroup)
-//   k_bin_scan     exclusive scan -> binptr[nbins+1]; clears the counters / cursors for the fill
-//   k_triplet_grad appends, per occurrence, the record {user, +-g_b, item} to its bin's list (one int atomic on
-//                  the bin cursor per occurrence)
-//   k_item_bin     per bin: walks its record list (contiguous), gathers the user rows, accumulates
-//                     acc[row][0:k] += +-g*gamma_u    acc[row][k:k+d] += +-g*theta_u    acc[row][k+d] += +-g
-//                  in LDS (ds_add_f32), then finishes each of its rows in one coalesced pass: the L2-regularised
-//                  gradient is applied to Gi/Bi in place (sgd) or stored to the staging tables (adam), and the W row
-//                  of the backward projection is written once (bf16 for the MFMA path), all-zero rows included, so
-//                  W needs no clearing and no conversion pass.
-// The user side reads pre-update item rows in k_triplet_grad, which has completed before k_item_bin starts.
-// Global float atomics moved 1032 of the 1544 B per triplet at ~1 TB/s (the chip-wide atomic rate); here the same
-// bytes are plain row gathers.
+// Item-side gradients without global float atomics ("occurrence segments").
+//   k_row_count    the returning count atomic gives every occurrence its rank within its item
+//   k_seg_alloc    the rank-0 occurrence reserves a contiguous segment of cnt[item] entries (wave-aggregated bump)
+//   k_triplet_grad writes, per occurrence, the 8-byte entry {user | role << 31, g_b} at seg_ptr[item] + rank
+//   k_item_seg     one group per occurrence; the rank-0 group of an item walks the item's segment, gathers the user
+//                  rows and accumulates in registers
+//                     acc_g += +-g*gamma_u     acc_t += +-g*theta_u     gsum += +-g
+//                  then finishes the item in one pass: the L2-regularised gradient is applied to Gi/Bi in place (sgd) or
+//                  stored to the staging tables (adam), and the W row of the backward projection is written once
+//                  (bf16 for the MFMA path: no conversion pass; untouched rows come from one memset of the bf16 image).
+// The user side reads pre-update item rows in k_triplet_grad, which has completed before k_item_seg starts.
+// Global float atomics moved 1032 of the 1544 B per triplet at ~1 TB/s (the chip-wide atomic rate); here the same bytes
+// are plain 16-B-per-lane row gathers.  Items hotter than SEG_CAP occurrences keep the excess on the atomic path
+// (bounded serial walk per group); k_item_seg folds the staged excess in and re-zeroes it.
 // ------------------------------------------------------------------------------------------------------------
-struct BinRec { int32_t u; float sg; int32_t item; int32_t pad; };   // 16 B
-
-__global__ __launch_bounds__(256) void k_bin_count(const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
-                                                   int64_t B, int I, int shift, int nbins, int32_t *__restrict__ cnt) {
-  extern __shared__ int hist[];
-  for (int e = threadIdx.x; e < nbins; e += 256) hist[e] = 0;
-  __syncthreads();
-  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
-    int i = pos[b], j = neg[b];                        // same clamping as clamp_idx(): counts must match the appends
-    i = i < 0 ? 0 : (i >= I ? I - 1 : i);
-    j = j < 0 ? 0 : (j >= I ? I - 1 : j);
-    atomicAdd(&hist[i >> shift], 1);
-    atomicAdd(&hist[j >> shift], 1);
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nbins; e += 256)
-    if (hist[e]) atomicAdd(cnt + e, hist[e]);
-}
-
-// one workgroup: binptr = exclusive scan of cnt; cnt (reused as the fill cursors) is cleared.
-__global__ __launch_bounds__(1024) void k_bin_scan(int32_t *__restrict__ cnt, int32_t *__restrict__ binptr, int nbins) {
-  __shared__ int part[1024];
-  const int per = (nbins + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = min(nbins, lo + per);
-  int s = 0;
-  for (int e = lo; e < hi; ++e) s += cnt[e];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan of the 1024 partial sums
-    const int v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int run = part[threadIdx.x] - s;
-  for (int e = lo; e < hi; ++e) {
-    const int c = cnt[e];
-    binptr[e] = run;
-    run += c;
-    cnt[e] = 0;
-  }
-  if (threadIdx.x == 1023) binptr[nbins] = part[1023];
-}
-
 template <int G, bool ADAM>
-__global__ __launch_bounds__(256) void k_item_bin(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
+__global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
                                                   float *__restrict__ Wf, uint16_t *__restrict__ Wb,
-                                                  const int32_t *__restrict__ binptr, const BinRec *__restrict__ recs,
-                                                  int shift, int RS, float lr) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int R = 1 << shift;
-  float *acc = reinterpret_cast<float *>(lds_raw);                        // [R][RS]
-  int *cnt = reinterpret_cast<int *>(acc + (size_t)R * RS);               // [R][2]  occurrences as i / as j
-  const int tid = threadIdx.x;
-  const int r0 = blockIdx.x << shift;
-  const int nrows = min(R, a.I - r0);
+                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B,
+                                                  float lr) {
+  const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (job >= 2 * B) return;
+  if (a.seg_rank[job] != 0) return;                                   // the rank-0 occurrence owns the item
+  const int item = clamp_quiet(job < B ? pos[job] : neg[job - B], a.I);
+  const int n = a.cntI[item];
+  const int ns = n < SEG_CAP ? n : SEG_CAP;
+  const int2 *ent = a.seg_ent + a.seg_ptr[item];
   const int k = a.k, d = a.d;
-  for (int e = tid; e < R * RS; e += 256) acc[e] = 0.f;
-  for (int e = tid; e < 2 * R; e += 256) cnt[e] = 0;
-  __syncthreads();
-  const int NG = 256 / G, gid = tid / G, gl = tid % G;
-  const int e0 = binptr[blockIdx.x], e1 = binptr[blockIdx.x + 1];
-  for (int e = e0 + gid; e < e1; e += NG) {
-    const BinRec rec = recs[e];
-    const int row = rec.item - r0;
-    const float gb = rec.sg;
-    const float *gu = a.Gu + (size_t)rec.u * k;
-    float *ar = acc + (size_t)row * RS;
-    for (int c = gl; c < k; c += G) atomicAdd(ar + c, gb * gu[c]);
-    if (d) {
-      const float *tu = a.Tu + (size_t)rec.u * d;
-      for (int c = gl; c < d; c += G) atomicAdd(ar + k + c, gb * tu[c]);
+  const int c4 = lane * 4;
+  const bool hk = c4 < k, hd = c4 < d;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), at = ag;
+  float gsum = 0.f;
+  int nj = 0;
+  int e = 0;
+  for (; e + 2 <= ns; e += 2) {                                       // two entries in flight
+    const int2 r0 = ent[e], r1 = ent[e + 1];
+    const int u0 = r0.x & 0x7fffffff, u1 = r1.x & 0x7fffffff;
+    const float s0 = r0.x < 0 ? -__int_as_float(r0.y) : __int_as_float(r0.y);
+    const float s1 = r1.x < 0 ? -__int_as_float(r1.y) : __int_as_float(r1.y);
+    nj += (r0.x < 0) + (r1.x < 0);
+    gsum += s0 + s1;
+    if (hk) {
+      const float4 p0 = ld4(a.Gu + (size_t)u0 * k + c4), p1 = ld4(a.Gu + (size_t)u1 * k + c4);
+      ag.x += s0 * p0.x + s1 * p1.x; ag.y += s0 * p0.y + s1 * p1.y; ag.z += s0 * p0.z + s1 * p1.z; ag.w += s0 * p0.w + s1 * p1.w;
     }
-    if (gl == 0) {
-      atomicAdd(ar + k + d, gb);
-      atomicAdd(cnt + 2 * row + (rec.pad ? 1 : 0), 1);
+    if (hd) {
+      const float4 p0 = ld4(a.Tu + (size_t)u0 * d + c4), p1 = ld4(a.Tu + (size_t)u1 * d + c4);
+      at.x += s0 * p0.x + s1 * p1.x; at.y += s0 * p0.y + s1 * p1.y; at.z += s0 * p0.z + s1 * p1.z; at.w += s0 * p0.w + s1 * p1.w;
     }
   }
-  __syncthreads();
-  const float reg = a.reg, r2 = 2.f * reg;
-  for (int e = tid; e < nrows * RS; e += 256) {
-    const int row = e / RS, c = e - row * RS;
-    const int item = r0 + row;
-    const int ni = cnt[2 * row], nj = cnt[2 * row + 1];
-    const float v = acc[e];
-    if (c < k) {
-      if (ni + nj) {
-        const size_t o = (size_t)item * k + c;
-        const float p = Gi[o];
-        const float grad = v + r2 * (float)(ni + nj) * p;
-        if (ADAM) a.dGi[o] = grad; else Gi[o] = p - lr * grad;
-      }
-    } else {
-      const int wc = c - k;
-      if (d) {
-        if (Wb) Wb[(size_t)item * a.PS + wc] = f2bf_s(wc <= d ? v : 0.f);
-        else Wf[(size_t)item * a.PS + wc] = wc <= d ? v : 0.f;
-      }
-      if (wc == d && (ni + nj)) {
-        const float p = Bi[item];
-        const float grad = v + r2 * (float)ni * p + (r2 * 0.1f) * (float)nj * p;
-        if (ADAM) a.dBi[item] = grad; else Bi[item] = p - lr * grad;
-      }
+  if (e < ns) {
+    const int2 r0 = ent[e];
+    const int u0 = r0.x & 0x7fffffff;
+    const float s0 = r0.x < 0 ? -__int_as_float(r0.y) : __int_as_float(r0.y);
+    nj += (r0.x < 0);
+    gsum += s0;
+    if (hk) {
+      const float4 p0 = ld4(a.Gu + (size_t)u0 * k + c4);
+      ag.x += s0 * p0.x; ag.y += s0 * p0.y; ag.z += s0 * p0.z; ag.w += s0 * p0.w;
     }
+    if (hd) {
+      const float4 p0 = ld4(a.Tu + (size_t)u0 * d + c4);
+      at.x += s0 * p0.x; at.y += s0 * p0.y; at.z += s0 * p0.z; at.w += s0 * p0.w;
+    }
+  }
+  const bool over = n > SEG_CAP;                                      // staged excess of a hot item
+  const float r2 = 2.f * a.reg;
+  const float fn = (float)ns, fj = (float)nj, fi = (float)(ns - nj);
+  if (hk) {
+    const size_t o = (size_t)item * k + c4;
+    const float4 q = ld4(Gi + o);
+    float4 gr = make_float4(ag.x + r2 * fn * q.x, ag.y + r2 * fn * q.y, ag.z + r2 * fn * q.z, ag.w + r2 * fn * q.w);
+    if (over) {
+      const float4 st = ld4(a.dGi + o);
+      gr.x += st.x; gr.y += st.y; gr.z += st.z; gr.w += st.w;
+    }
+    if (ADAM) *reinterpret_cast<float4 *>(a.dGi + o) = gr;
+    else {
+      *reinterpret_cast<float4 *>(Gi + o) = make_float4(q.x - lr * gr.x, q.y - lr * gr.y, q.z - lr * gr.z, q.w - lr * gr.w);
+      if (over) *reinterpret_cast<float4 *>(a.dGi + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (d) {
+    const size_t o = (size_t)item * a.PS;
+    float wl = gsum;                                                  // column d: the Bp column of [theta_u | 1]
+    if (over) {
+      if (hd) {
+        const float4 st = ld4(a.W + o + c4);
+        at.x += st.x; at.y += st.y; at.z += st.z; at.w += st.w;
+        if (Wb) *reinterpret_cast<float4 *>(a.W + o + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (lane == 0) { wl += a.W[o + d]; if (Wb) a.W[o + d] = 0.f; }
+    }
+    if (Wb) {
+      if (hd) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf_s(at.x) | ((uint32_t)f2bf_s(at.y) << 16);
+        pk.y = (uint32_t)f2bf_s(at.z) | ((uint32_t)f2bf_s(at.w) << 16);
+        *reinterpret_cast<uint2 *>(Wb + o + c4) = pk;
+      }
+      if (lane == 0) Wb[o + d] = f2bf_s(wl);
+    } else {
+      if (hd) *reinterpret_cast<float4 *>(Wf + o + c4) = at;
+      if (lane == 0) Wf[o + d] = wl;
+    }
+  }
+  if (lane == 0) {
+    const float p = Bi[item];
+    float gr = gsum + r2 * fi * p + (r2 * 0.1f) * fj * p;
+    if (over) gr += a.dBi[item];
+    if (ADAM) a.dBi[item] = gr;
+    else { Bi[item] = p - lr * gr; if (over) a.dBi[item] = 0.f; }
+    a.cntI[item] = 0;                                                 // reset for the next step
+    if (over) a.flagI[item] = 0u;
   }
 }
 
@@ -565,7 +602,12 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.fastI = h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD);
   a.lr = h->cfg.lr;
   a.item_atomics = h->item_mode ? 0 : 1;
-  a.binptr = h->binptr; a.bincur = h->bincnt; a.binrec = h->binrec; a.bin_shift = h->bin_shift;
+  if (h->item_mode) {
+    // every item row is finished by k_item_seg, which gathers PRE-update user rows after k_triplet_grad: the user
+    // side may therefore not be updated in place either (staging + k_apply_sgd)
+    a.fastI = 0; a.fastU = 0; a.fast = 0;
+  }
+  a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent;
   return a;
 }
 
@@ -647,63 +689,52 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   SparseArgs a = make_args(h, h->P);
   const bool vec = vec_ok(h);
   const int G = pick_group(a.k, a.d, vec);
-  if (h->fast_rows) {
+  if (h->fast_rows || h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
     hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI,
-                       a.fastU, a.fastI);
+                       a.fastU, a.fastI, h->item_mode ? h->seg_rank : (int32_t *)nullptr);
+  }
+  if (h->item_mode) {
+    BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
+    BPRX_HIP(h, hipMemsetAsync(h->seg_cursor, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_seg_alloc, dim3((unsigned)((2 * B + 1023) / 1024)), dim3(1024), 0, s, i, j, B, a.I, h->seg_rank, h->cntI,
+                       h->seg_ptr, h->seg_cursor);
   }
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
-  // W must be all-zero here: k_cast_W (backward variants >= 8) re-zeroes it while converting; other variants don't
-  if (a.d && !h->item_mode && (h->bwd_variant < 8 || h->cfg.feat_dtype != BPRX_F_BF16))
+  // W (fp32) must be all-zero here.  bf16 features: k_cast_W (backward variants >= 8) re-zeroes it while converting and
+  // k_item_seg re-zeroes the rows it folds in, so only the remaining combinations need the memset.
+  const bool bf = h->cfg.feat_dtype == BPRX_F_BF16;
+  if (a.d && (!bf || (!h->item_mode && h->bwd_variant < 8)))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
   return BPRX_OK;
 }
 
-int bprx_launch_bin_index(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
-  if (!h->item_mode) return BPRX_OK;
-  BprxProfScope ps(h, BPRX_PHASE_BIN_INDEX, s);
-  int64_t blocks = (B + 256 * 8 - 1) / (256 * 8);
-  if (blocks > 256) blocks = 256;
-  if (blocks < 1) blocks = 1;
-  BPRX_HIP(h, hipMemsetAsync(h->bincnt, 0, (size_t)h->bin_count * sizeof(int32_t), s));   // cursors of the last step
-  hipLaunchKernelGGL(k_bin_count, dim3((unsigned)blocks), dim3(256), h->bin_count * sizeof(int), s, i, j, B, h->cfg.num_items,
-                     h->bin_shift, h->bin_count, h->bincnt);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, h->bincnt, h->binptr, h->bin_count);
-  BPRX_LAUNCH_CHECK(h, "k_bin_count/k_bin_scan");
-  return BPRX_OK;
-}
-
-int bprx_launch_item_bin(bprx_handle *h, float lr_t, hipStream_t s) {
+int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, float lr_t, hipStream_t s) {
   if (!h->item_mode) return BPRX_OK;
   SparseArgs a = make_args(h, nullptr);
-  const bool vec = vec_ok(h);
-  const int G = pick_group(a.k, a.d, vec);
+  const int G = pick_group(a.k, a.d, true);
   const bool adam = h->cfg.optimizer == BPRX_OPT_ADAM_TF23;
   const bool bf = h->cfg.feat_dtype == BPRX_F_BF16;
   float *Wf = a.d && !bf ? h->W : nullptr;
   uint16_t *Wb = a.d && bf ? (uint16_t *)h->Wb : nullptr;
-  BprxProfScope ps(h, BPRX_PHASE_ITEM_BIN, s);
-#define LAUNCH_BIN(GG, AD)                                                                                              \
-  do {                                                                                                                  \
-    auto kfn = k_item_bin<GG, AD>;                                                                                      \
-    if (h->bin_lds > 48 * 1024)                                                                                         \
-      (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, h->bin_lds);             \
-    hipLaunchKernelGGL(kfn, dim3(h->bin_count), dim3(256), h->bin_lds, s, a, h->t.Gi, h->t.Bi, Wf, Wb, h->binptr,       \
-                       (const BinRec *)h->binrec, h->bin_shift, h->bin_rs, lr_t);                                       \
+  BprxProfScope ps(h, BPRX_PHASE_ITEM_SEG, s);
+  if (Wb) BPRX_HIP(h, hipMemsetAsync(Wb, 0, (size_t)a.I * a.PS * sizeof(uint16_t), s));   // rows of untouched items
+  const dim3 grid = grid_for(2 * B, G);
+#define LAUNCH_SEG(GG)                                                                                                   \
+  do {                                                                                                                   \
+    if (adam) hipLaunchKernelGGL((k_item_seg<GG, true>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t); \
+    else hipLaunchKernelGGL((k_item_seg<GG, false>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t);     \
   } while (0)
-#define LAUNCH_BIN_G(AD)                        \
-  switch (G) {                                  \
-    case 8: LAUNCH_BIN(8, AD); break;           \
-    case 16: LAUNCH_BIN(16, AD); break;         \
-    case 32: LAUNCH_BIN(32, AD); break;         \
-    default: LAUNCH_BIN(64, AD); break;         \
+  switch (G) {
+    case 8: LAUNCH_SEG(8); break;
+    case 16: LAUNCH_SEG(16); break;
+    case 32: LAUNCH_SEG(32); break;
+    default: LAUNCH_SEG(64); break;
   }
-  if (adam) { LAUNCH_BIN_G(true) } else { LAUNCH_BIN_G(false) }
-#undef LAUNCH_BIN_G
-#undef LAUNCH_BIN
-  BPRX_LAUNCH_CHECK(h, "k_item_bin");
+#undef LAUNCH_SEG
+  BPRX_LAUNCH_CHECK(h, "k_item_seg");
   return BPRX_OK;
 }
 
@@ -715,7 +746,7 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     const bool vec = vec_ok(h);
     const int G = pick_group(a.k, a.d, vec);
     // first_kind = 1 skips the user rows (their gradients are exported to the caller: BPRX_FLAG_EXPORT_USER_GRAD)
-    // item rows are finished in place by k_item_bin when that mode is on: kinds [fk, ek)
+    // item rows are finished in place by k_item_seg when that mode is on: kinds [fk, ek)
     const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
     const int ek = (h->item_mode || (h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 3;
     if (ek > fk)

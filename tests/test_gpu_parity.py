@@ -209,6 +209,38 @@ def test_sgd_mostly_exclusive_rows_with_some_duplicates(model):
     e.sync_check()
 
 
+@pytest.mark.parametrize("model,opt,item_mode", [("bprmf", "sgd", 1), ("bprmf", "adam_tf23", 1), ("vbpr", "sgd", 1),
+                                                 ("vbpr", "adam_tf23", 1), ("vbpr", "sgd", 0), ("bprmf", "sgd", 0)])
+def test_hot_items_segments_and_atomic_excess(model, opt, item_mode, monkeypatch):
+    """Item-side gradients by occurrence segments (item_mode 1, the default) and by global atomics (0) give the same
+    batch-synchronous step.  One item occurs 180 times (as positive AND as negative): more than the 64 entries a
+    segment is walked for, so its excess goes through the atomic staging tables and is folded in by k_item_seg."""
+    monkeypatch.setenv("BPRX_ITEM_MODE", str(item_mode))
+    U, I, k, B = 400, 300, 32, 512
+    d, D = (20, 128) if model == "vbpr" else (0, 0)
+    t = _tables(U, I, k, d, D, seed=13, bf16=(model == "vbpr"))
+    kw = dict(embed_d=d, feat_dim=D, feat_dtype="bf16") if model == "vbpr" else {}
+    lr = 0.05 if opt == "sgd" else 0.01
+    e = _engine(model=model, num_users=U, num_items=I, embed_k=k, optimizer=opt, lr=lr, reg=1e-3, max_batch=B, **kw).bind(**t)
+    o = orc.OracleModel(**t, quant=1 if model == "vbpr" else 0)
+    for step in range(3):
+        u, i, j = _batch(U, I, B, 60 + step)
+        i[:100] = 3
+        j[100:180] = 3
+        j[5] = 3                                       # i == j on the hot item
+        i[200:270] = 7                                 # a second hot item, one role only
+        loss = e.step(_dev(u), _dev(i), _dev(j)).item()
+        want = o.step(u, i, j, opt, lr, 1e-3)
+        assert loss == pytest.approx(want, rel=1e-4 if d else 2e-5)
+        rt, at = (2e-5, 2e-6) if not d else (2e-3, 1e-4)
+        if opt != "sgd":
+            at = max(at, 2e-3 * lr)
+        of, oa = (1e-3, 3 * lr) if (d and opt != "sgd") else (0.0, 0.0)
+        for n in (("Gu", "Gi", "Bi", "Tu", "E", "Bp") if d else ("Gu", "Gi", "Bi")):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step), of, oa)
+    e.sync_check()
+
+
 def test_device_eval_matches_reference_golden(golden_dir):
     """bprx_eval_users fed with the SAME score matrices the reference's own Evaluator was run on
     (tests/golden/gen_golden.py): per-user metrics averaged exactly like Evaluator.py:189-193, ties included."""
