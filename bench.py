@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam_tf23"])
-    ap.add_argument("--sampler", default="philox", choices=["philox", "epoch", "pregen"],
+    ap.add_argument("--sampler", default="epoch", choices=["philox", "epoch", "pregen"],
                     help="philox: device sampler, i.i.d. uniform interactions, inside the timed step; epoch: device "
                          "epoch-walk sampler (the reference's visiting order: user-grouped batches); pregen: resident "
                          "pre-generated index batches")

@@ -88,8 +88,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (h->SK > 256) h->SK = 256;
     // defaults = the fastest measured variants (profiles/r01_sweeps.md): forward v6 (asm-pinned ping-pong pipeline,
     // staggered chunk order; falls back to v1 when D % 256 != 0), backward v3 (bf16 W, conflict-free LDS image).
-    h->fwd_variant = 10;
-    h->bwd_variant = 8;
+    h->fwd_variant = 12;   // v8: one balanced 5..8-wave workgroup per CU, staggered chunk order (falls back to v6 / v1)
+    h->bwd_variant = 26;   // v3, 8 waves (256 columns) per workgroup, 2 tiles in flight, XCD-aware split placement
     if (const char *e = getenv("BPRX_FWD_VARIANT")) h->fwd_variant = atoi(e);
     if (const char *e = getenv("BPRX_BWD_VARIANT")) h->bwd_variant = atoi(e);
     A(dalloc_zero(&h->dTu, U * d));
@@ -113,10 +113,13 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     // default whenever the row widths fit the 16-B-per-lane layout and the item rows are not staging rows of a sharded
     // run.  BPRX_ITEM_MODE=0 forces the atomic staging path (A/B measurements: profiles/r01_sweeps.md).
     const bool fits = k % 4 == 0 && d % 4 == 0 && k <= 256 && d <= 256;
-    h->item_mode = (fits && !(cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 0;
-    if (const char *e = getenv("BPRX_ITEM_MODE")) h->item_mode = h->item_mode && atoi(e);
-    if (h->item_mode && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
-    if (h->item_mode) {
+    // seg_policy: 0 never, 1 per step (segments when the batch revisits items: 2B >= I; sparse batches keep the atomic
+    // staging path with its in-place update of exclusive rows -- C3 shard: 0.104 vs 0.121 ms/step), 2 always
+    h->seg_policy = (fits && !(cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 0;
+    if (const char *e = getenv("BPRX_ITEM_MODE")) { const int v = atoi(e); h->seg_policy = h->seg_policy ? (v < 0 ? 0 : (v > 2 ? 2 : v)) : 0; }
+    h->item_mode = 0;
+    if (h->seg_policy && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
+    if (h->seg_policy) {
       bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_ptr, I) == hipSuccess &&
                  dalloc_zero(&h->seg_cursor, (size_t)1) == hipSuccess &&
                  dalloc_zero((int2 **)&h->seg_ent, (size_t)2 * MB) == hipSuccess;
@@ -144,6 +147,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   {
     const char *e = getenv("BPRX_SIDE_STREAM");
     if (!(e && atoi(e))) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
+  }
+  {
+    hipDeviceProp_t prop;
+    h->num_cu = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
@@ -253,6 +260,7 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
   }
   h->proj_fresh = false;
+  h->item_mode = h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items);
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, h->cfg.lr, s))) return rc;             // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward

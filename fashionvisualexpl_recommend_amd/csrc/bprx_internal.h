@@ -39,12 +39,14 @@ struct bprx_handle {
   int SK;
   int fast_rows;                  // sgd: rows used by exactly one triplet of the batch are updated in place
   int32_t *cntU, *cntI;           // [U], [I] row multiplicities of the current batch (all-zero between steps)
-  int item_mode;                  // 1: item-side gradients by per-item occurrence segments (k_item_seg), 0: global
+  int seg_policy;                 // 0 never, 1 per step (2B >= I), 2 always (env BPRX_ITEM_MODE)
+  int item_mode;                  // this step: 1: item-side gradients by per-item occurrence segments (k_item_seg), 0: global
                                   //    float atomics into the staging tables + claim-apply
   int32_t *seg_rank;              // [2 * max_batch] rank of occurrence (role*B + b) among its item's occurrences
   int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent (valid for items of the current batch)
   int32_t *seg_cursor;            // [1] bump allocator of segments
   void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
+  int num_cu;                     // compute units of the device (balanced forward grid)
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
   // side stream: the sparse optimizer pass (k_apply_sgd / adam sweeps: factor tables only) runs beside the backward

@@ -231,21 +231,34 @@ struct WsStride3 {                     // bytes; >= NT*32 + 128 and == 32 (mod 2
   static constexpr int bytes = ((NT * 32 + 128 - 32 + 255) / 256) * 256 + 32;
 };
 
-template <int NT, int BTV>
-__global__ __launch_bounds__(256) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
+// NW waves per workgroup, 32 feature columns per wave: a workgroup owns NW*32 columns, so every W tile it loads from L2
+// serves NW*32 columns (NW = 8: half the W re-read traffic of NW = 4; W tiles are 5/8 of an F tile at NW = 4, NT = 5).
+template <int NT, int BTV, int NW, int PD>
+__global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
                                                           const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
-                                                          int rows_per_split, int descend) {
-  constexpr int FSB = 288;                           // F tile row stride, bytes (128 columns + 32)
+                                                          int rows_per_split, int descend, int xcd_map) {
+  constexpr int NTH = NW * 64, MC = NW * 32;         // threads, feature columns per workgroup
+  constexpr int FCH = MC / 8;                        // 16-B pieces per F tile row
+  constexpr int FSB = MC * 2 + 32;                   // F tile row stride, bytes (== 32 mod 256)
   constexpr int WSB = WsStride3<NT>::bytes;
-  constexpr int FPT = BTV * 16 / 256;                // 16-B F pieces per thread and tile
+  constexpr int FPT = BTV * FCH / NTH;               // 16-B F pieces per thread and tile
   constexpr int WCH = NT * 2;                        // 16-B pieces per W row
-  constexpr int WPT = (BTV * WCH + 255) / 256;
+  constexpr int WPT = (BTV * WCH + NTH - 1) / NTH;
   __shared__ __attribute__((aligned(16))) unsigned char Fs[BTV * FSB];
   __shared__ __attribute__((aligned(16))) unsigned char Ws[BTV * WSB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
-  const int m0 = blockIdx.x * 128;
-  const int tbeg = blockIdx.y * rows_per_split;
+  // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (own L2 each) in dispatch order.  The
+  // column ranges of one item split read the same W rows, so they are placed on ONE XCD (W re-fetched 8x otherwise:
+  // +65 MB of HBM/MALL fetch per launch measured on C2).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_map && gridDim.y % 8 == 0) {
+    const int flat = blockIdx.x + gridDim.x * blockIdx.y, xcd = flat & 7, slot = flat >> 3;
+    by = (slot / (int)gridDim.x) * 8 + xcd;
+    bx = slot % (int)gridDim.x;
+  }
+  const int m0 = bx * MC;
+  const int tbeg = by * rows_per_split;
   int tend = tbeg + rows_per_split;
   if (tend > nrows) tend = nrows;
   const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
@@ -254,40 +267,64 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16_v3(const uint16_t *__rest
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint4 freg[FPT], wreg[WPT];
-  auto issue = [&](int tile) {
-    const int t0 = tbeg + (descend ? (ntiles - 1 - tile) : tile) * BTV;
+  // PD tiles are in flight per workgroup (registers: PD * (FPT + WPT) * 4 VGPRs): the loop is latency-bound on the
+  // global loads, so bytes in flight per CU set the delivered bandwidth
+  uint4 freg[PD][FPT], wreg[PD][WPT];
+  // Loads are unconditional (rows / tiles past the end are clamped to the last valid one and zeroed at commit):
+  // with a load inside a divergent branch the compiler waits for vmcnt(0) at every commit and the pipeline collapses.
+#define BWD3_ISSUE(ST, TILE)                                                                                             \
+  {                                                                                                                      \
+    int tile_ = (TILE);                                                                                                  \
+    tile_ = tile_ < ntiles ? tile_ : ntiles - 1;                                                                         \
+    const int t0 = tbeg + (descend ? (ntiles - 1 - tile_) : tile_) * BTV;                                                \
+    _Pragma("unroll") for (int x = 0; x < FPT; ++x) {                                                                    \
+      const int idx = threadIdx.x + x * NTH, tr = idx / FCH, ch = idx % FCH;                                             \
+      int t = t0 + tr;                                                                                                   \
+      t = t < tend ? t : tend - 1;                                                                                       \
+      freg[ST][x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);                                   \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
+      int idx = threadIdx.x + x * NTH;                                                                                   \
+      idx = idx < BTV * WCH ? idx : BTV * WCH - 1;                                                                       \
+      const int tr = idx / WCH, ch = idx % WCH;                                                                          \
+      int t = t0 + tr;                                                                                                   \
+      t = t < tend ? t : tend - 1;                                                                                       \
+      wreg[ST][x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);                                      \
+    }                                                                                                                    \
+  }
+#define BWD3_COMMIT(ST, TILE)                                                                                            \
+  {                                                                                                                      \
+    const int tile_ = (TILE);                                                                                            \
+    const int t0 = tile_ < ntiles ? tbeg + (descend ? (ntiles - 1 - tile_) : tile_) * BTV : tend;                        \
+    _Pragma("unroll") for (int x = 0; x < FPT; ++x) {                                                                    \
+      const int idx = threadIdx.x + x * NTH, tr = idx / FCH, ch = idx % FCH;                                             \
+      const uint32_t mk = (t0 + tr < tend) ? 0xffffffffu : 0u;                                                           \
+      uint4 v = freg[ST][x];                                                                                             \
+      v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;                                                                        \
+      *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = v;                                     \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
+      const int idx = threadIdx.x + x * NTH, tr = idx / WCH, ch = idx % WCH;                                             \
+      const uint32_t mk = (t0 + tr < tend) ? 0xffffffffu : 0u;                                                           \
+      uint4 v = wreg[ST][x];                                                                                             \
+      v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;                                                                        \
+      if (idx < BTV * WCH) *reinterpret_cast<uint4 *>(&Ws[tr * WSB + ((tr & 8) << 4) + ch * 16]) = v;                    \
+    }                                                                                                                    \
+  }
+  if (ntiles == 0) {                                  // empty split: zero slab
+    float *slab0 = part + ((size_t)by * D + m0) * PS;
+    for (int e = threadIdx.x; e < MC * PS; e += NTH) slab0[e] = 0.f;
+    return;
+  }
 #pragma unroll
-    for (int x = 0; x < FPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15, t = t0 + tr;
-      freg[x] = make_uint4(0, 0, 0, 0);
-      if (t < tend) freg[x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
-    }
+  for (int st = 0; st < PD; ++st) BWD3_ISSUE(st, st)
+  for (int tile0 = 0; tile0 < ntiles; tile0 += PD) {
 #pragma unroll
-    for (int x = 0; x < WPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH, t = t0 + tr;
-      wreg[x] = make_uint4(0, 0, 0, 0);
-      if (idx < BTV * WCH && t < tend) wreg[x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int x = 0; x < FPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx >> 4, ch = idx & 15;
-      *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = freg[x];
-    }
-#pragma unroll
-    for (int x = 0; x < WPT; ++x) {
-      const int idx = threadIdx.x + x * 256, tr = idx / WCH, ch = idx % WCH;
-      if (idx < BTV * WCH) *reinterpret_cast<uint4 *>(&Ws[tr * WSB + ((tr & 8) << 4) + ch * 16]) = wreg[x];
-    }
-  };
-  if (ntiles > 0) issue(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
+   for (int st = 0; st < PD; ++st) {                 // tiles past the end are all-zero: computed, harmless
     __syncthreads();
-    commit();
+    BWD3_COMMIT(st, tile0 + st)
     __syncthreads();
-    if (tile + 1 < ntiles) issue(tile + 1);
+    BWD3_ISSUE(st, tile0 + st + PD)
 #pragma unroll
     for (int kk = 0; kk < BTV / 32; ++kk) {
       const int rlo = kk * 32 + 8 * g + qq, rhi = rlo + 4;       // (rlo & 8) == (rhi & 8) == 8*(g & 1)
@@ -310,8 +347,11 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16_v3(const uint16_t *__rest
         for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
       }
     }
+   }
   }
-  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
+#undef BWD3_ISSUE
+#undef BWD3_COMMIT
+  float *slab = part + ((size_t)by * D + m0) * PS;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -344,8 +384,32 @@ __device__ __forceinline__ void asm_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void asm_tie(i32x4 &r) { asm volatile("" : "+v"(r)); }
+// LDS read the compiler can neither sink nor serialize (it turns  read-all-then-MFMA  back into  read, wait, MFMA  per
+// fragment to save registers); completion is waited for with counted lgkmcnt (LDS operations return in order).
+__device__ __forceinline__ void asm_dsread(i32x4 &dst, const void *lds_ptr) {
+  const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void *)lds_ptr;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void asm_lgkmcnt(int n) {   // n is a constant after unrolling: one case survives
+  switch (n) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
+  }
+}
 
-template <int NT, int MT>
+// ABL: compile-time timing-only ablations (wrong results): 1 no global loads after the first issue, 2 no MFMA,
+// 4 no LDS reads, 8 no LDS writes
+template <int NT, int MT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                           int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
                                                           float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
@@ -367,7 +431,10 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
   const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
   const int nch = D / KC;
-  const int cshift = stagger ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
+  const int cshift = (stagger & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
+  const bool nobar = stagger & 2;                       // timing-only ablations (wrong results): no barriers /
+  const int amask = (stagger & 4) ? 0 : -1;             // every A load re-reads chunk 0 (cache hits)
+  const int bmask = (stagger & 8) ? 0 : -1;             // every B load re-reads chunk 0
   auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -378,31 +445,43 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
 #define V6_ISSUE(c_, BR, AR)                                                                                          \
   {                                                                                                                   \
     const int k1 = kof(c_);                                                                                           \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, k1 + bk, NT * 16)]);      \
+    if (!(ABL & 1) || c_ == 0) {                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, (k1 & bmask) + bk, NT * 16)]);      \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
+        asm_gload(AR[ks][mt], arow[mt] + (k1 & amask) + ks * 32);                                                               \
+    }                                                                                                                 \
   }
 #define V6_PARK(buf_, BR, NWAIT)                                                                                      \
   {                                                                                                                   \
-    asm_vmcnt<NWAIT>();                                                                                               \
+    if (!(ABL & 1)) asm_vmcnt<NWAIT>();                                                                               \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_tie(BR[t]);                                                    \
+    if (!(ABL & 8))                                                                                                   \
     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
         *reinterpret_cast<i32x4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
   }
 #define V6_COMPUTE(buf_, AR, NWAIT)                                                                                   \
   {                                                                                                                   \
-    asm_vmcnt<NWAIT>();                                                                                               \
+    if (!(ABL & 1)) asm_vmcnt<NWAIT>();                                                                               \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
         asm_tie(AR[ks][mt]);                                                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
-        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][(nt * 16 + r) * BSS + ks * 32 + q * 8]);         \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[ks][mt]), b,          \
-                                                                 acc[mt][nt], 0, 0, 0);                               \
-      }                                                                                                               \
+    /* B fragments stream from LDS through a window of LWIN reads in flight; fragment f = ks*NT + nt */               \
+    i32x4 bfr[KS * NT];                                                                                               \
+    if (!(ABL & 4))                                                                                                   \
+    _Pragma("unroll") for (int f = 0; f < LWIN && f < KS * NT; ++f)                                                   \
+        asm_dsread(bfr[f], &Bs[buf_][((f % NT) * 16 + r) * BSS + (f / NT) * 32 + q * 8]);                             \
+    _Pragma("unroll") for (int f = 0; f < KS * NT; ++f) {                                                             \
+      const int left = KS * NT - 1 - f;                                                                               \
+      if (!(ABL & 4)) asm_lgkmcnt(left < LWIN - 1 ? left : LWIN - 1);                                                 \
+      asm_tie(bfr[f]);                                                                                                \
+      if (!(ABL & 2))                                                                                                 \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                               \
+          acc[mt][f % NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[f / NT][mt]),       \
+                                                                    __builtin_bit_cast(bf16x8, bfr[f]), acc[mt][f % NT], 0, 0, 0); \
+      if (!(ABL & 4) && f + LWIN < KS * NT)                                                                           \
+        asm_dsread(bfr[f + LWIN], &Bs[buf_][(((f + LWIN) % NT) * 16 + r) * BSS + ((f + LWIN) / NT) * 32 + q * 8]);    \
     }                                                                                                                 \
   }
+  constexpr int LWIN = 10;   // LDS reads in flight per wave (lgkmcnt counts to 15)
   constexpr int NA = KS * MT, NALL = NT + KS * MT;
   V6_ISSUE(0, bX, aX)
   V6_PARK(0, bX, NA)
@@ -414,12 +493,12 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
     V6_ISSUE(c + 1, bY, aY)
     V6_COMPUTE(0, aX, NALL)
     V6_PARK(1, bY, NA)
-    __syncthreads();
+    if (!nobar) __syncthreads();
     const int cn = c + 2 < nch ? c + 2 : nch - 1;
     V6_ISSUE(cn, bX, aX)
     V6_COMPUTE(1, aY, NALL)
     V6_PARK(0, bX, NA)
-    __syncthreads();
+    if (!nobar) __syncthreads();
   }
   asm_vmcnt<0>();
 #pragma unroll
@@ -441,6 +520,143 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// forward v8: the v6 pipeline on ONE 8-wave workgroup per CU with a balanced share of the 16-row tiles.
+// Measured (scripts/fwd_scale.py, scripts/probe/ldpat.hip, profiles/r01_sweeps.md): v6 streams F at the ~4.9 TB/s this
+// access pattern reaches on the chip ONLY when every CU holds the same number of workgroups (32768 or 65536 items);
+// co-resident workgroups do not overlap, so 50000 items = 391 workgroups of 128 items (two on 135 CUs, one on the
+// rest) take as long as 65536 items.  Here every CU gets T/G tiles (+-1) and reads the [E|Bp]^T chunks once.
+//   grid G (= #CUs while T <= 16 G); workgroup g owns tiles [g*T/G, (g+1)*T/G), at most 16, and has as many waves
+//   (5..8) as give every wave TWO tiles (one when the launch is small): the waves walk the chunks in lockstep, so a
+//   wave with one tile among waves with two buys nothing (12 tiles on 8 waves: 95.6 us; on 6-7 waves: see sweeps).
+//   The pipeline body is instantiated for 2 and for 1 row tile and picked per wave (same barrier sequence in both) --
+//   a repeated dummy tile would cost its full load-issue time.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int V8_NWMIN = 5;   // workgroups of 5..8 waves (the launcher picks the count that gives every wave two tiles)
+template <int NT, int MT>
+__device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const uint16_t *__restrict__ Et, uint16_t (*Bs)[NT * 16 * (KC + 16)],
+                                        f32x4 (&acc)[2][NT], int D, int cshift, int r, int q) {
+  constexpr int BSS = KC + 16;
+  constexpr int KS = KC / 32;
+  constexpr int NPIECE = NT * 16 * (KC / 8);              // 16-B pieces of one [E|Bp]^T chunk (contiguous in Et)
+  constexpr int NBP = (NPIECE + V8_NWMIN * 64 - 1) / (V8_NWMIN * 64);   // pieces per thread for the smallest workgroup;
+  int bofs[NBP], lofs[NBP];                               // surplus slots clamp onto piece NPIECE-1 (one address per wave)
+#pragma unroll
+  for (int x = 0; x < NBP; ++x) {
+    int pc = threadIdx.x + x * (int)blockDim.x;
+    pc = pc < NPIECE ? pc : NPIECE - 1;
+    bofs[x] = pc * 8;
+    lofs[x] = (pc / (KC / 8)) * BSS + (pc % (KC / 8)) * 8;
+  }
+  const int nch = D / KC;
+  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
+  i32x4 bX[NBP], bY[NBP], aX[KS][MT], aY[KS][MT];
+#define V8_ISSUE(c_, BR, AR)                                                                                          \
+  {                                                                                                                   \
+    const int k1 = kof(c_);                                                                                           \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_gload(BR[x], &Et[(size_t)(k1 >> 7) * (NT * 16 * 128) + bofs[x]]); \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
+  }
+#define V8_PARK(buf_, BR, NWAIT)                                                                                      \
+  {                                                                                                                   \
+    asm_vmcnt<NWAIT>();                                                                                               \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_tie(BR[x]);                                                   \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) *reinterpret_cast<i32x4 *>(&Bs[buf_][lofs[x]]) = BR[x];           \
+  }
+#define V8_COMPUTE(buf_, AR, NWAIT)                                                                                   \
+  {                                                                                                                   \
+    asm_vmcnt<NWAIT>();                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        asm_tie(AR[ks][mt]);                                                                                          \
+    i32x4 bfr[KS * NT];                                                                                               \
+    _Pragma("unroll") for (int f = 0; f < LWIN8 && f < KS * NT; ++f)                                                  \
+        asm_dsread(bfr[f], &Bs[buf_][((f % NT) * 16 + r) * BSS + (f / NT) * 32 + q * 8]);                             \
+    _Pragma("unroll") for (int f = 0; f < KS * NT; ++f) {                                                             \
+      const int left = KS * NT - 1 - f;                                                                               \
+      asm_lgkmcnt(left < LWIN8 - 1 ? left : LWIN8 - 1);                                                               \
+      asm_tie(bfr[f]);                                                                                                \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                               \
+          acc[mt][f % NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[f / NT][mt]),       \
+                                                                    __builtin_bit_cast(bf16x8, bfr[f]), acc[mt][f % NT], 0, 0, 0); \
+      if (f + LWIN8 < KS * NT)                                                                                        \
+        asm_dsread(bfr[f + LWIN8], &Bs[buf_][(((f + LWIN8) % NT) * 16 + r) * BSS + ((f + LWIN8) / NT) * 32 + q * 8]); \
+    }                                                                                                                 \
+  }
+  constexpr int LWIN8 = 8;
+  constexpr int NA = KS * MT, NALL = NBP + KS * MT;
+  V8_ISSUE(0, bX, aX)
+  V8_PARK(0, bX, NA)
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {            // straight-line body (see v6); nch is even
+    V8_ISSUE(c + 1, bY, aY)
+    V8_COMPUTE(0, aX, NALL)
+    V8_PARK(1, bY, NA)
+    __syncthreads();
+    const int cn = c + 2 < nch ? c + 2 : nch - 1;
+    V8_ISSUE(cn, bX, aX)
+    V8_COMPUTE(1, aY, NALL)
+    V8_PARK(0, bX, NA)
+    __syncthreads();
+  }
+  asm_vmcnt<0>();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm_tie(aX[ks][mt]);
+#undef V8_ISSUE
+#undef V8_PARK
+#undef V8_COMPUTE
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v8(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger,
+                                                          int tiles_per_wave) {
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * (KC + 16)];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int T = (nrows + 15) >> 4;
+  const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
+  int tile[2];
+  const uint16_t *arow[2];
+  const int first = t0 + w * tiles_per_wave;                               // tiles_per_wave is 1 or 2
+  const int nlive = (first < t1 ? 1 : 0) + ((tiles_per_wave == 2 && first + 1 < t1) ? 1 : 0);   // wave-uniform
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    tile[mt] = first + mt;
+    if (tile[mt] >= t1) tile[mt] = t1 > t0 ? t1 - 1 : 0;                  // only read by a wave without work
+    int t = tile[mt] * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + (size_t)item * D + q * 8;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
+  const int nch = D / KC;
+  const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nlive == 2) v8_body<NT, 2>(arow, Et, Bs, acc, D, cshift, r, q);
+  else v8_body<NT, 1>(arow, Et, Bs, acc, D, cshift, r, q);               // nlive == 0: a spare wave repeats a tile
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (mt >= nlive) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = tile[mt] * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+      }
+    }
+  }
+}
 
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
@@ -501,9 +717,41 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   dim3 grid((unsigned)((nrows + 4 * MT * 16 - 1) / (4 * MT * 16)));
   // the pipelined kernel only where the build verified it spill-free (build.py), and D must hold an even chunk count
-  const bool pipe = (v == 2 || v == 3) && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(6, NT, MT, 0);
-  if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1);
-  else if (pipe) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1);
+  const bool pipe = (v == 2 || v == 3 || v == 4) && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(6, NT, MT, 0);
+  if constexpr (NT == 5) {
+    static const int abl = getenv("BPRX_FWD_ABL") ? atoi(getenv("BPRX_FWD_ABL")) : 0;
+    if (pipe && MT != 1 && abl) {
+      switch (abl) {
+        case 1: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 2: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 2>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 3: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 3>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 4: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 4>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 6: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 6>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 7: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 7>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 14: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 14>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 15: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 15>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        default: break;
+      }
+    }
+  }
+  if constexpr (NT <= 9) {
+    // v == 4: v8 (one balanced workgroup of 5..8 waves per CU)
+    if (v == 4 && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(8, NT, 0, 0)) {
+      const int64_t T = (nrows + 15) / 16;
+      const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+      int64_t G = (T + 15) / 16;
+      if (G < ncu) G = T < ncu ? T : ncu;
+      else G = (G + ncu - 1) / ncu * ncu;
+      const int tpw_max = (int)((T + G - 1) / G);                 // most tiles any workgroup owns (<= 16)
+      const int per_wave = tpw_max > 8 ? 2 : 1;
+      int nw = (tpw_max + per_wave - 1) / per_wave;
+      if (nw < V8_NWMIN) nw = V8_NWMIN;
+      hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, per_wave);
+      return 0;
+    }
+  }
+  if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15);
+  else if (pipe) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15);
   else if (MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
   return 0;
@@ -513,18 +761,36 @@ template <int NT>
 int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, I = h->cfg.num_items;
   // bwd_variant: 0 = v1 (fp32 W, no prefetch); 8 = v3 (bf16 W, conflict-free LDS image, next tile prefetched),
-  //              9 = v3 with 64-item tiles; +4 = walk the items in descending order
+  //              9 = v3 with 64-item tiles; +2 = 8 waves / 256 columns per workgroup; +4 = descending item order
   const int desc = (h->bwd_variant >> 2) & 1;
   if (h->bwd_variant >= 8) {
-    const int bt3 = (h->bwd_variant & 3) == 1 ? 64 : 32;
+    const int bt3 = (h->bwd_variant & 1) ? 64 : 32;
     int rps3 = (I + h->SK - 1) / h->SK;
     rps3 = (rps3 + bt3 - 1) / bt3 * bt3;
     const size_t n4 = (size_t)I * h->PS / 4;
     if (!h->item_mode)   // k_item_seg has already written Wb (bf16) itself
       hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
-    dim3 g3(D / 128, h->SK);
-    if (bt3 == 32) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
-    else hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 64>), g3, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc);
+    // bwd_variant & 2: 8 waves / 256 columns per workgroup (needs D % 256 == 0); bits 4-5: tiles in flight - 1
+    const bool w8 = (h->bwd_variant & 2) && D % 256 == 0;
+    const int pd = ((h->bwd_variant >> 4) & 3) + 1;
+    const int xmap = (h->bwd_variant & 64) ? 0 : 1;   // +64: plain blockIdx mapping (A/B)
+    dim3 g3(D / (w8 ? 256 : 128), h->SK);
+#define BWD3_LAUNCH(BTV_, NW_, PD_)                                                                                      \
+  hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_>), g3, dim3(NW_ * 64), 0, s, (const uint16_t *)h->t.F, I, D, \
+                     (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap)
+#define BWD3_PD(BTV_, NW_)                                        \
+  switch (pd) {                                                   \
+    case 1: BWD3_LAUNCH(BTV_, NW_, 1); break;                     \
+    case 2: BWD3_LAUNCH(BTV_, NW_, 2); break;                     \
+    case 3: BWD3_LAUNCH(BTV_, NW_, 3); break;                     \
+    default: BWD3_LAUNCH(BTV_, NW_, 4); break;                    \
+  }
+    if (bt3 == 32 && w8) { BWD3_PD(32, 8) }
+    else if (bt3 == 32) { BWD3_PD(32, 4) }
+    else if (w8) { BWD3_LAUNCH(64, 8, 1); }
+    else { BWD3_LAUNCH(64, 4, 1); }
+#undef BWD3_PD
+#undef BWD3_LAUNCH
     return 0;
   }
   int rps = (I + h->SK - 1) / h->SK;

@@ -181,11 +181,13 @@ def test_philox_sampler_bit_exact_vs_cpu_twin():
         assert b in tr[a] and c not in tr[a]
 
 
-@pytest.mark.parametrize("model", ["bprmf", "vbpr"])
-def test_sgd_mostly_exclusive_rows_with_some_duplicates(model):
+@pytest.mark.parametrize("model,item_mode", [("bprmf", 1), ("vbpr", 1), ("bprmf", 2), ("vbpr", 2)])
+def test_sgd_mostly_exclusive_rows_with_some_duplicates(model, item_mode, monkeypatch):
     """Sparse batches (U, I >> B): most rows are used by exactly one triplet and take the in-place fast path, a few are
     shared (duplicates, i == j, an item used as positive and as negative) and take the staging path.  Both must give
-    the batch-synchronous result of the oracle."""
+    the batch-synchronous result of the oracle.  item_mode 1 keeps this sparse batch (2B < I) on the atomic path with
+    the in-place update of exclusive rows; 2 forces the occurrence segments."""
+    monkeypatch.setenv("BPRX_ITEM_MODE", str(item_mode))
     U, I, k, B = 6000, 9000, 32, 512
     d, D = (20, 128) if model == "vbpr" else (0, 0)
     t = _tables(U, I, k, d, D, seed=11, bf16=(model == "vbpr"))
@@ -209,11 +211,12 @@ def test_sgd_mostly_exclusive_rows_with_some_duplicates(model):
     e.sync_check()
 
 
-@pytest.mark.parametrize("model,opt,item_mode", [("bprmf", "sgd", 1), ("bprmf", "adam_tf23", 1), ("vbpr", "sgd", 1),
-                                                 ("vbpr", "adam_tf23", 1), ("vbpr", "sgd", 0), ("bprmf", "sgd", 0)])
+@pytest.mark.parametrize("model,opt,item_mode", [("bprmf", "sgd", 2), ("bprmf", "adam_tf23", 2), ("vbpr", "sgd", 2),
+                                                 ("vbpr", "adam_tf23", 2), ("vbpr", "sgd", 0), ("bprmf", "sgd", 0),
+                                                 ("vbpr", "sgd", 1)])
 def test_hot_items_segments_and_atomic_excess(model, opt, item_mode, monkeypatch):
-    """Item-side gradients by occurrence segments (item_mode 1, the default) and by global atomics (0) give the same
-    batch-synchronous step.  One item occurs 180 times (as positive AND as negative): more than the 64 entries a
+    """Item-side gradients by occurrence segments (BPRX_ITEM_MODE 2 = always; 1 = per step when 2B >= I, the default)
+    and by global atomics (0) give the same batch-synchronous step.  One item occurs 180 times (as positive AND as negative): more than the 64 entries a
     segment is walked for, so its excess goes through the atomic staging tables and is folded in by k_item_seg."""
     monkeypatch.setenv("BPRX_ITEM_MODE", str(item_mode))
     U, I, k, B = 400, 300, 32, 512
