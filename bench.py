@@ -30,6 +30,10 @@ WORKLOADS = {
     "c2": dict(model="vbpr", U=100_000, I=50_000, k=64, d=64, D=4096, dtype="bf16", B=65_536),
     # BASELINE.json configs[2] per-GPU shard shape (BPRMF k=128, 5M x 1M over 8 GPUs -> 625K users/GPU)
     "c3shard": dict(model="bprmf", U=625_000, I=1_000_000, k=128, d=0, D=0, dtype="fp32", B=65_536),
+    # BASELINE.json configs[3] per-GPU shard shape (VBPR k=128, 2M x 500K over 8 GPUs -> 250K users, 62.5K items/GPU)
+    "c4shard": dict(model="vbpr", U=250_000, I=62_500, k=128, d=128, D=4096, dtype="bf16", B=65_536),
+    # BASELINE.json configs[4] shape with bf16 features (k = d = 256; the fp8 projection is not built yet)
+    "c5bf16": dict(model="vbpr", U=100_000, I=50_000, k=256, d=256, D=4096, dtype="bf16", B=65_536),
 }
 
 

@@ -533,14 +533,14 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
 //   The pipeline body is instantiated for 2 and for 1 row tile and picked per wave (same barrier sequence in both) --
 //   a repeated dummy tile would cost its full load-issue time.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int V8_NWMIN = 5;   // workgroups of 5..8 waves (the launcher picks the count that gives every wave two tiles)
-template <int NT, int MT>
+// NWMIN: smallest workgroup (waves) the launcher may pick for this instantiation (fixes the B pieces per thread)
+template <int NT, int MT, int NWMIN>
 __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const uint16_t *__restrict__ Et, uint16_t (*Bs)[NT * 16 * (KC + 16)],
                                         f32x4 (&acc)[2][NT], int D, int cshift, int r, int q) {
   constexpr int BSS = KC + 16;
   constexpr int KS = KC / 32;
   constexpr int NPIECE = NT * 16 * (KC / 8);              // 16-B pieces of one [E|Bp]^T chunk (contiguous in Et)
-  constexpr int NBP = (NPIECE + V8_NWMIN * 64 - 1) / (V8_NWMIN * 64);   // pieces per thread for the smallest workgroup;
+  constexpr int NBP = (NPIECE + NWMIN * 64 - 1) / (NWMIN * 64);   // pieces per thread for the smallest workgroup;
   int bofs[NBP], lofs[NBP];                               // surplus slots clamp onto piece NPIECE-1 (one address per wave)
 #pragma unroll
   for (int x = 0; x < NBP; ++x) {
@@ -584,7 +584,7 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
         asm_dsread(bfr[f + LWIN8], &Bs[buf_][(((f + LWIN8) % NT) * 16 + r) * BSS + ((f + LWIN8) / NT) * 32 + q * 8]); \
     }                                                                                                                 \
   }
-  constexpr int LWIN8 = 8;
+  constexpr int LWIN8 = NT <= 7 ? 8 : 4;   // LDS fragment reads in flight (register budget of the wide instantiations)
   constexpr int NA = KS * MT, NALL = NBP + KS * MT;
   V8_ISSUE(0, bX, aX)
   V8_PARK(0, bX, NA)
@@ -610,8 +610,10 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
 #undef V8_COMPUTE
 }
 
-template <int NT>
-__global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v8(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+// NWMAX = 8 (two waves per SIMD, 256 registers each) up to NT = 9; NWMAX = 4 (one wave per SIMD, the unified 512-register
+// file: accumulators in AGPRs) for the wide projections (d >= 112).
+template <int NT, int NWMAX>
+__global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                           int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
                                                           float *__restrict__ P, int PS, int32_t *errflag, int stagger,
                                                           int tiles_per_wave) {
@@ -642,8 +644,9 @@ __global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v8(const uint16_t *__r
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (nlive == 2) v8_body<NT, 2>(arow, Et, Bs, acc, D, cshift, r, q);
-  else v8_body<NT, 1>(arow, Et, Bs, acc, D, cshift, r, q);               // nlive == 0: a spare wave repeats a tile
+  constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
+  if (nlive == 2) v8_body<NT, 2, NWMIN>(arow, Et, Bs, acc, D, cshift, r, q);
+  else v8_body<NT, 1, NWMIN>(arow, Et, Bs, acc, D, cshift, r, q);        // nlive == 0: a spare wave repeats a tile
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     if (mt >= nlive) continue;
@@ -734,19 +737,21 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
       }
     }
   }
-  if constexpr (NT <= 9) {
-    // v == 4: v8 (one balanced workgroup of 5..8 waves per CU)
-    if (v == 4 && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(8, NT, 0, 0)) {
+  {
+    // v == 4: v8 (one balanced workgroup per CU; 5..8 waves up to NT = 7, 4 waves with the 512-register file above)
+    constexpr int NWMAX = NT <= 9 ? 8 : 4;
+    constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
+    if (v == 4 && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(8, NT, NWMAX, 0)) {
       const int64_t T = (nrows + 15) / 16;
       const int ncu = h->num_cu > 0 ? h->num_cu : 256;
-      int64_t G = (T + 15) / 16;
+      int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
       if (G < ncu) G = T < ncu ? T : ncu;
       else G = (G + ncu - 1) / ncu * ncu;
-      const int tpw_max = (int)((T + G - 1) / G);                 // most tiles any workgroup owns (<= 16)
-      const int per_wave = tpw_max > 8 ? 2 : 1;
+      const int tpw_max = (int)((T + G - 1) / G);                 // most tiles any workgroup owns (<= 2 NWMAX)
+      const int per_wave = tpw_max > NWMAX ? 2 : 1;
       int nw = (tpw_max + per_wave - 1) / per_wave;
-      if (nw < V8_NWMIN) nw = V8_NWMIN;
-      hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, per_wave);
+      if (nw < NWMIN) nw = NWMIN;
+      hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, per_wave);
       return 0;
     }
   }

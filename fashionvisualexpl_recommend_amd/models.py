@@ -120,8 +120,16 @@ class BPRMF(RecommenderModel):
             else:
                 self.engine.t[n].copy_(v)
 
+    def weights_path(self, epoch):
+        rec = getattr(self.params, "rec", self.model_kind)
+        return os.path.join(configs.weight_dir(), self.params.dataset, rec, f'weights-{epoch}-{self.directory_parameters}.pt')
+
     # ---- BPRMF.py:127-192 ------------------------------------------------------------------------------------------
-    def train(self):
+    def train(self, resume=False):
+        """The reference's training loop.  `resume=True` (the reference parses --restore_epochs but
+        never restores, BPRMF.py:130): continue from the snapshot `weights-{restore_epochs}-...pt` -- tables, Adam slots
+        and step counter are reloaded and the deterministic triplet stream is fast-forwarded by restore_epochs epochs,
+        so the remaining epochs see exactly the batches an uninterrupted run would."""
         max_metrics = {'hr': 0, 'p': 0, 'r': 0, 'auc': 0, 'ndcg': 0}
         best_state = None
         best_epoch = self.restore_epochs
@@ -137,6 +145,13 @@ class BPRMF(RecommenderModel):
         rdir = os.path.join(configs.results_dir(), self.params.dataset, rec)
         os.makedirs(wdir, exist_ok=True)
         os.makedirs(rdir, exist_ok=True)
+        if resume:
+            path = self.weights_path(self.restore_epochs)
+            self.load_state_dict(torch.load(path, map_location=self.engine.device, weights_only=True))
+            for _ in range(self.restore_epochs * steps_per_epoch):
+                next(next_batch)
+            it = self.restore_epochs + 1
+            print('Restored epoch {0} from {1}'.format(self.restore_epochs, path))
         start_ep = time()
         print('Start training...')
         for batch in next_batch:

@@ -40,3 +40,33 @@ def test_c1_bprmf_metric_parity(tmp_path, opt, lr, capsys):
         np.testing.assert_allclose(model.engine.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1),
                                    rtol=5e-3, atol=2e-5, err_msg=n)
     assert want["hr_t"] > 0.05 and got["hr_t"] > 0.05          # ~20x the random-ranking level: the comparison is informative
+
+
+@pytest.mark.parametrize("opt,lr", [("adam_tf23", 5e-3), ("sgd", 0.5)])
+def test_resume_continues_the_same_run(tmp_path, opt, lr):
+    """a run interrupted after epoch 2 and resumed from its snapshot (tables, Adam slots, step counter,
+    fast-forwarded triplet stream) ends where the uninterrupted 4-epoch run ends."""
+    from fashionvisualexpl_recommend_amd.dataset import DataLoader
+    from fashionvisualexpl_recommend_amd.models import BPRMF
+    tr, va, te = synth.make_interactions_clustered(300, 500, per_user=14, clusters=10, p_in=0.9, seed=7)
+    synth.write_dataset(str(tmp_path), "c1r", tr, va, te, 500)
+    configs.set_roots(str(tmp_path), str(tmp_path / "results"))
+
+    def params(epochs, restore):
+        return Namespace(dataset="c1r", validation=True, batch_size=128, epochs=epochs, batch_eval=128, embed_k=16, lr=lr,
+                         reg=1e-3, top_k=10, verbose=2, restore_epochs=restore, rec="bprmf", best_metric="ndcg",
+                         optimizer=opt, init_seed=0)
+    full = BPRMF(DataLoader(params(4, 1)), params(4, 1))
+    res_full = full.train()
+    first = BPRMF(DataLoader(params(2, 1)), params(2, 1))
+    first.train()                                                    # writes weights-2-*.pt (verbose=2)
+    second = BPRMF(DataLoader(params(4, 2)), params(4, 2))
+    res = second.train(resume=True)
+    assert sorted(res) == [3, 4]
+    if opt == "adam_tf23":
+        assert second.engine.adam_step == full.engine.adam_step
+    for n in ("Gu", "Gi", "Bi"):
+        np.testing.assert_allclose(second.engine.t[n].cpu().numpy(), full.engine.t[n].cpu().numpy(), rtol=1e-4, atol=1e-5,
+                                   err_msg=n)
+    for key in ("hr_t", "ndcg_t", "auc_t"):
+        assert abs(res[4][key] - res_full[4][key]) <= 1e-3
