@@ -32,8 +32,11 @@ WORKLOADS = {
     "c3shard": dict(model="bprmf", U=625_000, I=1_000_000, k=128, d=0, D=0, dtype="fp32", B=65_536),
     # BASELINE.json configs[3] per-GPU shard shape (VBPR k=128, 2M x 500K over 8 GPUs -> 250K users, 62.5K items/GPU)
     "c4shard": dict(model="vbpr", U=250_000, I=62_500, k=128, d=128, D=4096, dtype="bf16", B=65_536),
-    # BASELINE.json configs[4] shape with bf16 features (k = d = 256; the fp8 projection is not built yet)
+    # BASELINE.json configs[4]: VBPR k = d = 256, fp8 (e4m3fn) feature table resident in HBM; and its bf16 twin
+    "c5": dict(model="vbpr", U=100_000, I=50_000, k=256, d=256, D=4096, dtype="fp8", B=65_536),
     "c5bf16": dict(model="vbpr", U=100_000, I=50_000, k=256, d=256, D=4096, dtype="bf16", B=65_536),
+    # configs[1] shape with fp8 features (what the fp8 table buys on the headline shape)
+    "c2fp8": dict(model="vbpr", U=100_000, I=50_000, k=64, d=64, D=4096, dtype="fp8", B=65_536),
 }
 
 
@@ -58,7 +61,7 @@ def parse():
 def algorithmic_bytes_per_triplet(w, B):
     """fused single pass, every touched row read once and (if trainable) written once, int32 indices."""
     k, d, D = w["k"], w["d"], w["D"]
-    s = {"fp32": 4, "bf16": 2}[w["dtype"]]
+    s = {"fp32": 4, "bf16": 2, "fp8": 1}[w["dtype"]]
     b = 24 * k + 28
     if w["model"] == "vbpr":
         b += 8 * d + 2 * D * s + 2.0 * (D * (d + 1)) * 4 / B
@@ -77,7 +80,8 @@ def make_state(w, device, seed, torch):
     t = dict(Gu=glorot(w["U"], w["k"]), Gi=glorot(w["I"], w["k"]), Bi=torch.zeros(w["I"], device=device))
     if w["model"] == "vbpr":
         I, D, d = w["I"], w["D"], w["d"]
-        F = torch.empty((I, D), device=device, dtype=torch.bfloat16 if w["dtype"] == "bf16" else torch.float32)
+        fdt = {"bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn}.get(w["dtype"], torch.float32)
+        F = torch.empty((I, D), device=device, dtype=torch.float32 if fdt == torch.float8_e4m3fn else fdt)
         mx = 0.0
         chunk = 8192
         for s in range(0, I, chunk):                      # chunked: never more than ~400 MB of fp32 temporaries
@@ -87,6 +91,11 @@ def make_state(w, device, seed, torch):
             mx = max(mx, float(f.max()))
             F[s:s + n] = f.to(F.dtype)
         F.div_(mx)
+        if fdt == torch.float8_e4m3fn:                    # e4m3fn codes of f * 448 (Engine's feat_scale default)
+            F8 = torch.empty((I, D), device=device, dtype=fdt)
+            for s in range(0, I, chunk):
+                F8[s:s + chunk] = (F[s:s + chunk] * 448.0).to(fdt)
+            F = F8
         t.update(Tu=glorot(w["U"], d), F=F, E=glorot(D, d), Bp=glorot(D, 1).reshape(-1))
     return t
 
@@ -220,11 +229,11 @@ def main():
         per_trip = algorithmic_bytes_per_triplet(w, B)
         kernels = {p: {"avg_ms": ms / n, "launches": n} for p, (ms, n) in prof.items()}
         dom = max(kernels, key=lambda p: kernels[p]["avg_ms"])
-        s = {"fp32": 4, "bf16": 2}[w["dtype"]]
+        s = {"fp32": 4, "bf16": 2, "fp8": 1}[w["dtype"]]
         if w["model"] == "vbpr":
             PS = 16 * ((w["d"] + 1 + 15) // 16)
             kern_bytes = {   # algorithmic bytes per launch, per kernel (DESIGN.md "Kernels")
-                "proj_fwd": w["I"] * (w["D"] * s + PS * 4) + PS * w["D"] * 2,
+                "proj_fwd": w["I"] * (w["D"] * s + PS * 4) + PS * w["D"] * min(s, 2),
                 "proj_bwd": w["I"] * (w["D"] * s + PS * 4) + w["D"] * PS * 4,
                 "triplet_grad": B * (24 * w["k"] + 28 + 8 * w["d"] + 2 * PS * 4 + 2 * PS * 4) / 1.0,
                 "apply": 3 * B * 0 + B * (12 * (w["k"] + w["d"]) + 24 * w["k"]),
@@ -282,8 +291,11 @@ def cpu_baseline(w, tables, steps, optimizer):
     cpu = lambda t, n: t[:n].float().cpu().numpy()
     kw = dict(Gu=cpu(tables["Gu"], U), Gi=cpu(tables["Gi"], I), Bi=cpu(tables["Bi"], I))
     if w["model"] == "vbpr":
-        kw.update(Tu=cpu(tables["Tu"], U), F=cpu(tables["F"], I), E=tables["E"].cpu().numpy(),
-                  Bp=tables["Bp"].cpu().numpy(), quant=1 if w["dtype"] == "bf16" else 0)
+        Fh = cpu(tables["F"], I)
+        if w["dtype"] == "fp8":
+            Fh = Fh / np.float32(448.0)
+        kw.update(Tu=cpu(tables["Tu"], U), F=Fh, E=tables["E"].cpu().numpy(),
+                  Bp=tables["Bp"].cpu().numpy(), quant={"bf16": 1, "fp8": 2}.get(w["dtype"], 0))
     o = orc.OracleModel(**kw)
     rs = np.random.RandomState(5)
     cores = orc.lib().orc_num_threads()

@@ -9,13 +9,13 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbprx.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2
 
 MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
-FEAT_DTYPE = {"fp32": 0, "bf16": 1}
+FEAT_DTYPE = {"fp32": 0, "bf16": 1, "fp8": 2}
 E_RANGE = -4
 PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count"]
 
@@ -31,7 +31,7 @@ class Config(C.Structure):
                 ("embed_k", C.c_int32), ("embed_d", C.c_int32), ("feat_dim", C.c_int32), ("feat_dtype", C.c_int32),
                 ("optimizer", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int64),
                 ("lr", C.c_float), ("reg", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("epsilon", C.c_float), ("flags", C.c_int32)]
+                ("epsilon", C.c_float), ("flags", C.c_int32), ("feat_scale", C.c_float)]
 
 
 TABLE_FIELDS = ["Gu", "Gi", "Bi", "Tu", "F", "E", "Bp", "m_Gu", "v_Gu", "m_Gi", "v_Gi", "m_Bi", "v_Bi",

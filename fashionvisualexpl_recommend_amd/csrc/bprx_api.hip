@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->cntU, h->cntI};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->qs, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->cntU, h->cntI};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -46,9 +46,13 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   if (vb) {
     if (cfg->embed_d <= 0 || cfg->feat_dim <= 0) CFAIL(BPRX_E_INVALID, "VBPR needs embed_d > 0 and feat_dim > 0");
     if (cfg->embed_d > 271) CFAIL(BPRX_E_INVALID, "embed_d %d > 271 unsupported", cfg->embed_d);
-    if (cfg->feat_dtype != BPRX_F_FP32 && cfg->feat_dtype != BPRX_F_BF16) CFAIL(BPRX_E_INVALID, "unknown feat_dtype");
+    if (cfg->feat_dtype != BPRX_F_FP32 && cfg->feat_dtype != BPRX_F_BF16 && cfg->feat_dtype != BPRX_F_FP8)
+      CFAIL(BPRX_E_INVALID, "unknown feat_dtype");
     if (cfg->feat_dtype == BPRX_F_BF16 && cfg->feat_dim % 128 != 0)
       CFAIL(BPRX_E_INVALID, "bf16 features need feat_dim %% 128 == 0 (got %d)", cfg->feat_dim);
+    if (cfg->feat_dtype == BPRX_F_FP8 && cfg->feat_dim % 256 != 0)
+      CFAIL(BPRX_E_INVALID, "fp8 features need feat_dim %% 256 == 0 (got %d)", cfg->feat_dim);
+    if (cfg->feat_dtype == BPRX_F_FP8 && !(cfg->feat_scale > 0.f)) CFAIL(BPRX_E_INVALID, "fp8 features need feat_scale > 0");
   }
   if ((cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) && cfg->optimizer != BPRX_OPT_SGD)
     CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_*_GRAD support optimizer sgd only");
@@ -100,6 +104,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     A(dalloc_zero((uint16_t **)&h->Et, PS * D));
     A(dalloc_zero(&h->dEp, D * d + D));
     A(dalloc_zero(&h->part, (size_t)h->SK * D * PS));
+    A(dalloc_zero(&h->qs, (size_t)4));
   }
 #undef A
   if (!ok) {
@@ -118,7 +123,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     h->seg_policy = (fits && !(cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 0;
     if (const char *e = getenv("BPRX_ITEM_MODE")) { const int v = atoi(e); h->seg_policy = h->seg_policy ? (v < 0 ? 0 : (v > 2 ? 2 : v)) : 0; }
     h->item_mode = 0;
-    if (h->seg_policy && vb && cfg->feat_dtype == BPRX_F_BF16 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
+    if (vb && cfg->feat_dtype == BPRX_F_FP8 && h->bwd_variant < 8) h->bwd_variant = 26;                 // fp8: v3 only
+    if (h->seg_policy && vb && cfg->feat_dtype != BPRX_F_FP32 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
     if (h->seg_policy) {
       bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_ptr, I) == hipSuccess &&
                  dalloc_zero(&h->seg_cursor, (size_t)1) == hipSuccess &&

@@ -21,6 +21,79 @@ __device__ __forceinline__ uint16_t f2bf(float x) {   // round-to-nearest-even; 
   return (uint16_t)(u >> 16);
 }
 
+// OCP e4m3fn code of x: round-to-nearest-even, saturating at +-448 (written out instead of v_cvt_pk_fp8_f32 so that
+// the CPU oracle's restatement is the same arithmetic bit for bit).  x is finite.
+__device__ __forceinline__ uint32_t f2e4m3(float x) {
+  const uint32_t u = __float_as_uint(x), sign = (u >> 24) & 0x80u, a = u & 0x7fffffffu;
+  const float ax = __uint_as_float(a);
+  if (ax < 0.015625f) return sign | (uint32_t)__builtin_rintf(ax * 512.0f);        // below 2^-6: multiples of 2^-9
+  const uint32_t rr = a + 0x7ffffu + ((a >> 20) & 1u);                             // keep 3 mantissa bits, RNE
+  const int e = (int)(rr >> 23) - 127;
+  const uint32_t m = (rr >> 20) & 7u;
+  if (e > 8 || (e == 8 && m == 7u)) return sign | 0x7eu;                           // 448
+  return sign | ((uint32_t)(e + 7) << 3) | m;
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(2))) long i64x2_t;
+// one 16-byte operand fragment per lane: 8 bf16 (one 16x16x32 MFMA) or 16 fp8 (two 16x16x32 fp8 MFMAs over the low and
+// the high 8 bytes; A and B fragments are cut the same way, so every k is paired with itself exactly once)
+template <bool F8>
+__device__ __forceinline__ f32x4 mfma_frag(i32x4_t a, i32x4_t b, f32x4 c) {
+  if constexpr (F8) {
+    const i64x2_t av = __builtin_bit_cast(i64x2_t, a), bv = __builtin_bit_cast(i64x2_t, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av.x, bv.x, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av.y, bv.y, c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+}
+
+// max |x| over E and Bp as the bit pattern of a non-negative float (monotonic as uint32): qs[0]
+__global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ E, size_t nE, const float *__restrict__ Bp, size_t nB,
+                                                uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nE + nB; e += (size_t)gridDim.x * 256) {
+    const float v = e < nE ? E[e] : Bp[e - nE];
+    const uint32_t a = __float_as_uint(v) & 0x7fffffffu;
+    m = a > m ? a : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+  __shared__ uint32_t wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {                               // one same-address atomic per workgroup (~15 ns each)
+    uint32_t b = wm[0];
+    for (int w = 1; w < 4; ++w) b = wm[w] > b ? wm[w] : b;
+    if (b) atomicMax(out, b);
+  }
+}
+
+// fp8 image of [E|Bp|0]^T: e4m3fn(x * sE), sE = 448 / max|E,Bp|, chunk-major with 256-wide chunks (256-byte rows: the
+// same BYTE layout as the bf16 image with 128-wide chunks, so the forward kernels are shared).  Block (0,0) also
+// publishes qs[1] = 1 / (feat_scale * sE), the factor that turns the fp8 products back into P.
+__global__ __launch_bounds__(256) void k_cast_Et8(const float *__restrict__ E, const float *__restrict__ Bp,
+                                                  uint8_t *__restrict__ Et, int D, int d, int PS, float *__restrict__ qs,
+                                                  float feat_scale) {
+  __shared__ float tile[64][17];
+  const float amax = qs[0];
+  const float sE = amax > 0.f ? 448.0f / amax : 1.0f;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) qs[1] = 1.0f / (feat_scale * sE);
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
+  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+    const int kr = idx >> 4, nc = idx & 15, kk = k0 + kr, n = n0 + nc;
+    float v = 0.f;
+    if (kk < D) v = n < d ? E[(size_t)kk * d + n] : (n == d ? Bp[kk] : 0.f);
+    tile[kr][nc] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+    const int nc = idx >> 6, kr = idx & 63, kk = k0 + kr, n = n0 + nc;
+    if (n < PS && kk < D) Et[((size_t)(kk >> 8) * PS + n) * 256 + (kk & 255)] = (uint8_t)f2e4m3(tile[kr][nc] * sE);
+  }
+}
+
 // [E|Bp|0]^T in bf16, stored CHUNK-MAJOR: element (n, k) at ((k/128)*PS + n)*128 + k%128, i.e. each 128-wide k-chunk
 // of all PS rows is one contiguous PS*256-byte block.  (A plain [PS][D] image has 8-KB rows: the rows of one chunk
 // then sit at a power-of-two stride and every workgroup's chunk load lands on the same few L2 channels.)
@@ -53,10 +126,13 @@ __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, co
 constexpr int KC = 128;          // k-chunk staged per barrier pair
 constexpr int BS_STRIDE = KC + 8;  // bf16 elements; 272-B rows keep ds_read_b128 nearly conflict-free (v1)
 
-template <int NT, int MT>
+// F8: the operands are fp8 (e4m3fn) bytes; F / Et are then addressed as if they were bf16 matrices of half the width
+// (D = feat_dim / 2: identical byte layout), and P is rescaled by *pscale.
+template <int NT, int MT, bool F8>
 __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                        int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                       float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
+                                                       float *__restrict__ P, int PS, int32_t *errflag, int stagger,
+                                                       const float *__restrict__ pscale) {
   __shared__ __attribute__((aligned(16))) uint16_t Bs[NT * 16 * BS_STRIDE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -101,10 +177,12 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
       for (int nt = 0; nt < NT; ++nt) {
         const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * BS_STRIDE + ks + q * 8]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = mfma_frag<F8>(__builtin_bit_cast(i32x4_t, a[mt]), __builtin_bit_cast(i32x4_t, b), acc[mt][nt]);
       }
     }
   }
+  const float ps = F8 ? *pscale : 1.0f;
   // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4)*4 + reg
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -113,7 +191,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
       const int t = row0 + mt * 16 + q * 4 + reg;
       if (t < nrows) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
       }
     }
 }
@@ -233,12 +311,23 @@ struct WsStride3 {                     // bytes; >= NT*32 + 128 and == 32 (mod 2
 
 // NW waves per workgroup, 32 feature columns per wave: a workgroup owns NW*32 columns, so every W tile it loads from L2
 // serves NW*32 columns (NW = 8: half the W re-read traffic of NW = 4; W tiles are 5/8 of an F tile at NW = 4, NT = 5).
-template <int NT, int BTV, int NW, int PD>
+// 16 fp8 (e4m3fn) -> 16 bf16, exact (hardware decode + truncation of an exactly representable value)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t w, uint32_t &o0, uint32_t &o1) {
+  const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  o0 = (__float_as_uint(a.x) >> 16) | (__float_as_uint(a.y) & 0xffff0000u);
+  o1 = (__float_as_uint(b.x) >> 16) | (__float_as_uint(b.y) & 0xffff0000u);
+}
+
+// F8: F holds fp8 codes (1 byte per element): the tile loads move half the bytes and the codes are widened to bf16 on
+// the way into LDS (W stays bf16); the slabs then hold (F*feat_scale)^T W and are rescaled where they are summed.
+template <int NT, int BTV, int NW, int PD, bool F8>
 __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
                                                           const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
                                                           int rows_per_split, int descend, int xcd_map) {
   constexpr int NTH = NW * 64, MC = NW * 32;         // threads, feature columns per workgroup
-  constexpr int FCH = MC / 8;                        // 16-B pieces per F tile row
+  constexpr int ESZ = F8 ? 1 : 2;                    // bytes per feature element in HBM
+  constexpr int FCH = MC * ESZ / 16;                 // 16-B pieces per F tile row (HBM side)
   constexpr int FSB = MC * 2 + 32;                   // F tile row stride, bytes (== 32 mod 256)
   constexpr int WSB = WsStride3<NT>::bytes;
   constexpr int FPT = BTV * FCH / NTH;               // 16-B F pieces per thread and tile
@@ -281,7 +370,8 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
       const int idx = threadIdx.x + x * NTH, tr = idx / FCH, ch = idx % FCH;                                             \
       int t = t0 + tr;                                                                                                   \
       t = t < tend ? t : tend - 1;                                                                                       \
-      freg[ST][x] = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);                                   \
+      freg[ST][x] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(F) +                       \
+                                                     ((size_t)t * D + m0) * ESZ + ch * 16);                             \
     }                                                                                                                    \
     _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
       int idx = threadIdx.x + x * NTH;                                                                                   \
@@ -301,7 +391,15 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
       const uint32_t mk = (t0 + tr < tend) ? 0xffffffffu : 0u;                                                           \
       uint4 v = freg[ST][x];                                                                                             \
       v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;                                                                        \
-      *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = v;                                     \
+      if constexpr (F8) {                                                                                                \
+        uint4 lo, hi;                                                                                                    \
+        fp8x4_to_bf16x4(v.x, lo.x, lo.y); fp8x4_to_bf16x4(v.y, lo.z, lo.w);                                              \
+        fp8x4_to_bf16x4(v.z, hi.x, hi.y); fp8x4_to_bf16x4(v.w, hi.z, hi.w);                                              \
+        *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 32) ^ ((tr & 8) << 4))]) = lo;                                  \
+        *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 32 + 16) ^ ((tr & 8) << 4))]) = hi;                             \
+      } else {                                                                                                           \
+        *reinterpret_cast<uint4 *>(&Fs[tr * FSB + ((ch * 16) ^ ((tr & 8) << 4))]) = v;                                   \
+      }                                                                                                                  \
     }                                                                                                                    \
     _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
       const int idx = threadIdx.x + x * NTH, tr = idx / WCH, ch = idx % WCH;                                             \
@@ -412,7 +510,8 @@ __device__ __forceinline__ void asm_lgkmcnt(int n) {   // n is a constant after 
 template <int NT, int MT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                           int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger) {
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger,
+                                                          const float *__restrict__ /*pscale: bf16 only*/) {
   constexpr int BSS = KC + 16;
   constexpr int KS = KC / 32;
   __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
@@ -534,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
 //   a repeated dummy tile would cost its full load-issue time.
 // ------------------------------------------------------------------------------------------------------------
 // NWMIN: smallest workgroup (waves) the launcher may pick for this instantiation (fixes the B pieces per thread)
-template <int NT, int MT, int NWMIN>
+template <int NT, int MT, int NWMIN, bool F8>
 __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const uint16_t *__restrict__ Et, uint16_t (*Bs)[NT * 16 * (KC + 16)],
                                         f32x4 (&acc)[2][NT], int D, int cshift, int r, int q) {
   constexpr int BSS = KC + 16;
@@ -578,8 +677,7 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
       asm_lgkmcnt(left < LWIN8 - 1 ? left : LWIN8 - 1);                                                               \
       asm_tie(bfr[f]);                                                                                                \
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                               \
-          acc[mt][f % NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[f / NT][mt]),       \
-                                                                    __builtin_bit_cast(bf16x8, bfr[f]), acc[mt][f % NT], 0, 0, 0); \
+          acc[mt][f % NT] = mfma_frag<F8>(AR[f / NT][mt], bfr[f], acc[mt][f % NT]);                                   \
       if (f + LWIN8 < KS * NT)                                                                                        \
         asm_dsread(bfr[f + LWIN8], &Bs[buf_][(((f + LWIN8) % NT) * 16 + r) * BSS + ((f + LWIN8) / NT) * 32 + q * 8]); \
     }                                                                                                                 \
@@ -612,11 +710,11 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
 
 // NWMAX = 8 (two waves per SIMD, 256 registers each) up to NT = 9; NWMAX = 4 (one wave per SIMD, the unified 512-register
 // file: accumulators in AGPRs) for the wide projections (d >= 112).
-template <int NT, int NWMAX>
+template <int NT, int NWMAX, bool F8>
 __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                           int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
                                                           float *__restrict__ P, int PS, int32_t *errflag, int stagger,
-                                                          int tiles_per_wave) {
+                                                          const float *__restrict__ pscale, int tiles_per_wave) {
   __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * (KC + 16)];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -645,8 +743,9 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
-  if (nlive == 2) v8_body<NT, 2, NWMIN>(arow, Et, Bs, acc, D, cshift, r, q);
-  else v8_body<NT, 1, NWMIN>(arow, Et, Bs, acc, D, cshift, r, q);        // nlive == 0: a spare wave repeats a tile
+  if (nlive == 2) v8_body<NT, 2, NWMIN, F8>(arow, Et, Bs, acc, D, cshift, r, q);
+  else v8_body<NT, 1, NWMIN, F8>(arow, Et, Bs, acc, D, cshift, r, q);    // nlive == 0: a spare wave repeats a tile
+  const float ps = F8 ? *pscale : 1.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     if (mt >= nlive) continue;
@@ -655,7 +754,7 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
       const int t = tile[mt] * 16 + q * 4 + reg;
       if (t < nrows) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
       }
     }
   }
@@ -663,13 +762,14 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
 
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
-                                                      float *__restrict__ dEp) {
+                                                      float *__restrict__ dEp, float gscale) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (size_t)D * PS) return;
   const int kk = (int)(e / PS), n = (int)(e % PS);
   if (n > d) return;
   float s = 0.f;
   for (int sidx = 0; sidx < SK; ++sidx) s += part[(size_t)sidx * D * PS + e];
+  s *= gscale;
   if (n < d) dEp[(size_t)kk * d + n] = s;
   else dEp[(size_t)D * d + kk] = s;
 }
@@ -709,7 +809,8 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
 
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
 
-#define FWD_ARGS (const uint16_t *)h->t.F, rows, (int)nrows, h->cfg.num_items, h->cfg.feat_dim, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
+// Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
+#define FWD_ARGS (const uint16_t *)h->t.F, rows, (int)nrows, h->cfg.num_items, Deq, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   constexpr int MTD = NT <= 9 ? 2 : 1;
@@ -717,22 +818,25 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   //              2 = v6 (asm-pinned ping-pong pipeline), 3 = v6 with one row tile per wave; +8 = staggered chunk order;
   //              +16 / +32 = v1 timing-only ablations (skip the B / A loads)
   const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3);
+  const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
+  const int Deq = f8 ? h->cfg.feat_dim / 2 : h->cfg.feat_dim;
+  const float *pscale = h->qs + 1;
   const int MT = (v == 1 || v == 3) ? 1 : MTD;
   dim3 grid((unsigned)((nrows + 4 * MT * 16 - 1) / (4 * MT * 16)));
   // the pipelined kernel only where the build verified it spill-free (build.py), and D must hold an even chunk count
-  const bool pipe = (v == 2 || v == 3 || v == 4) && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(6, NT, MT, 0);
+  const bool pipe = !f8 && (v == 2 || v == 3 || v == 4) && Deq % 256 == 0 && bprx_variant_safe(6, NT, MT, 0);
   if constexpr (NT == 5) {
     static const int abl = getenv("BPRX_FWD_ABL") ? atoi(getenv("BPRX_FWD_ABL")) : 0;
     if (pipe && MT != 1 && abl) {
       switch (abl) {
-        case 1: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 2: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 2>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 3: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 3>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 4: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 4>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 6: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 6>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 7: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 7>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 14: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 14>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
-        case 15: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 15>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15); return 0;
+        case 1: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 2: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 2>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 3: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 3>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 4: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 4>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 6: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 6>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 7: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 7>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 14: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 14>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
+        case 15: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 15>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
         default: break;
       }
     }
@@ -741,7 +845,7 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
     // v == 4: v8 (one balanced workgroup per CU; 5..8 waves up to NT = 7, 4 waves with the 512-register file above)
     constexpr int NWMAX = NT <= 9 ? 8 : 4;
     constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
-    if (v == 4 && h->cfg.feat_dim % 256 == 0 && bprx_variant_safe(8, NT, NWMAX, 0)) {
+    if (v == 4 && Deq % 256 == 0 && bprx_variant_safe(8, NT, NWMAX, f8 ? 1 : 0)) {
       const int64_t T = (nrows + 15) / 16;
       const int ncu = h->num_cu > 0 ? h->num_cu : 256;
       int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
@@ -751,14 +855,16 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
       const int per_wave = tpw_max > NWMAX ? 2 : 1;
       int nw = (tpw_max + per_wave - 1) / per_wave;
       if (nw < NWMIN) nw = NWMIN;
-      hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, per_wave);
+      if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, true>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, pscale, per_wave);
+      else hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, false>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, pscale, per_wave);
       return 0;
     }
   }
-  if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15);
-  else if (pipe) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15);
-  else if (MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg);
-  else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg);
+  if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale);
+  else if (pipe) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale);
+  else if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, true>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1, pscale);
+  else if (MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1, false>), grid, dim3(256), 0, s, FWD_ARGS, stg, pscale);
+  else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, false>), grid, dim3(256), 0, s, FWD_ARGS, stg, pscale);
   return 0;
 }
 
@@ -779,10 +885,15 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
     const bool w8 = (h->bwd_variant & 2) && D % 256 == 0;
     const int pd = ((h->bwd_variant >> 4) & 3) + 1;
     const int xmap = (h->bwd_variant & 64) ? 0 : 1;   // +64: plain blockIdx mapping (A/B)
+    const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
     dim3 g3(D / (w8 ? 256 : 128), h->SK);
 #define BWD3_LAUNCH(BTV_, NW_, PD_)                                                                                      \
-  hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_>), g3, dim3(NW_ * 64), 0, s, (const uint16_t *)h->t.F, I, D, \
-                     (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap)
+  do {                                                                                                                   \
+    if (f8) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_, true>), g3, dim3(NW_ * 64), 0, s,                 \
+                               (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap); \
+    else hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_, false>), g3, dim3(NW_ * 64), 0, s,                   \
+                            (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap);  \
+  } while (0)
 #define BWD3_PD(BTV_, NW_)                                        \
   switch (pd) {                                                   \
     case 1: BWD3_LAUNCH(BTV_, NW_, 1); break;                     \
@@ -829,10 +940,19 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
 }  // namespace
 
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
-  if (h->cfg.feat_dtype != BPRX_F_BF16) return BPRX_OK;
+  if (h->cfg.feat_dtype == BPRX_F_FP32) return BPRX_OK;
   const int D = h->cfg.feat_dim;
   BprxProfScope ps(h, BPRX_PHASE_CAST_ET, s);
   dim3 grid((D + 63) / 64, h->PS / 16);
+  if (h->cfg.feat_dtype == BPRX_F_FP8) {
+    BPRX_HIP(h, hipMemsetAsync(h->qs, 0, sizeof(float), s));
+    hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, h->t.E, (size_t)D * h->cfg.embed_d, h->t.Bp, (size_t)D,
+                       (uint32_t *)h->qs);
+    hipLaunchKernelGGL(k_cast_Et8, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint8_t *)h->Et, D, h->cfg.embed_d, h->PS, h->qs,
+                       h->cfg.feat_scale);
+    BPRX_LAUNCH_CHECK(h, "k_cast_Et8");
+    return BPRX_OK;
+  }
   hipLaunchKernelGGL(k_cast_Et, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint16_t *)h->Et, D, h->cfg.embed_d, h->PS);
   BPRX_LAUNCH_CHECK(h, "k_cast_Et");
   return BPRX_OK;
@@ -841,7 +961,7 @@ int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
 int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   if (nrows <= 0) return BPRX_OK;
   BprxProfScope ps(h, BPRX_PHASE_PROJ_FWD, s);
-  if (h->cfg.feat_dtype == BPRX_F_BF16) {
+  if (h->cfg.feat_dtype != BPRX_F_FP32) {
     const int NT = h->PS / 16;
 #define CALL(N) launch_fwd_nt<N>(h, rows, nrows, Pout, s)
     NT_SWITCH(NT, CALL)
@@ -858,7 +978,7 @@ int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, flo
 
 int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, d = h->cfg.embed_d, I = h->cfg.num_items;
-  if (h->cfg.feat_dtype == BPRX_F_BF16) {
+  if (h->cfg.feat_dtype != BPRX_F_FP32) {
     const int NT = h->PS / 16;
     {
       BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
@@ -870,7 +990,8 @@ int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s) {
     if (h->fused_reduce) return BPRX_OK;              // k_dense_update sums the slabs (bprx_step, bf16 path)
     const size_t n = (size_t)D * h->PS;
     BprxProfScope ps(h, BPRX_PHASE_REDUCE, s);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK, D, d, h->PS, h->dEp);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK, D, d, h->PS, h->dEp,
+                       h->cfg.feat_dtype == BPRX_F_FP8 ? 1.0f / h->cfg.feat_scale : 1.0f);
     BPRX_LAUNCH_CHECK(h, "k_reduce_parts");
   } else {
     BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
                                                       float *mBp, float *vBp, const float *__restrict__ dEp,
                                                       const float *__restrict__ part, int SK, int D, int d, int PS, int adam,
                                                       float lr_t, float reg, float b1, float b2, float eps,
-                                                      double *__restrict__ sqpart) {
+                                                      double *__restrict__ sqpart, float gscale) {
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   double sq = 0.0;
   const size_t total = (size_t)D * PS;
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
         for (int x = 0; x < 8; ++x) gsum += t[x];
       }
       for (; sidx < SK; ++sidx) gsum += part[(size_t)sidx * total + e];
+      gsum *= gscale;
     } else {
       gsum = n < d ? dEp[(size_t)kk * d + n] : dEp[(size_t)D * d + kk];
     }
@@ -703,7 +704,7 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
   // W (fp32) must be all-zero here.  bf16 features: k_cast_W (backward variants >= 8) re-zeroes it while converting and
   // k_item_seg re-zeroes the rows it folds in, so only the remaining combinations need the memset.
-  const bool bf = h->cfg.feat_dtype == BPRX_F_BF16;
+  const bool bf = h->cfg.feat_dtype != BPRX_F_FP32;     // bf16 W image (bf16 and fp8 features)
   if (a.d && (!bf || (!h->item_mode && h->bwd_variant < 8)))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
@@ -716,7 +717,7 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
   SparseArgs a = make_args(h, nullptr);
   const int G = pick_group(a.k, a.d, true);
   const bool adam = h->cfg.optimizer == BPRX_OPT_ADAM_TF23;
-  const bool bf = h->cfg.feat_dtype == BPRX_F_BF16;
+  const bool bf = h->cfg.feat_dtype != BPRX_F_FP32;     // bf16 W image (bf16 and fp8 features)
   float *Wf = a.d && !bf ? h->W : nullptr;
   uint16_t *Wb = a.d && bf ? (uint16_t *)h->Wb : nullptr;
   BprxProfScope ps(h, BPRX_PHASE_ITEM_SEG, s);
@@ -779,11 +780,13 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   h->dense_blocks = (int)blocks;
   BprxProfScope ps(h, BPRX_PHASE_DENSE, s);
   // fused_reduce: the split-K slabs are summed here (bprx_step); otherwise dEp holds the (all-reduced) gradient
-  const float *part = (h->fused_reduce && h->cfg.feat_dtype == BPRX_F_BF16) ? h->part : nullptr;
+  const float *part = (h->fused_reduce && h->cfg.feat_dtype != BPRX_F_FP32) ? h->part : nullptr;
+  // fp8 features: the slabs hold (F*feat_scale)^T W; an all-reduced dEp was already rescaled by k_reduce_parts
+  const float gscale = (part && h->cfg.feat_dtype == BPRX_F_FP8) ? 1.0f / h->cfg.feat_scale : 1.0f;
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
                      h->t.v_Bp, h->dEp, part, h->SK, h->cfg.feat_dim, h->cfg.embed_d, h->PS,
                      h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg, h->cfg.beta1, h->cfg.beta2,
-                     h->cfg.epsilon, h->loss_acc);
+                     h->cfg.epsilon, h->loss_acc, gscale);
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
   return BPRX_OK;
 }

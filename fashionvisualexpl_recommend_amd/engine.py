@@ -34,7 +34,7 @@ def as_index(x, device):
 class Engine:
     def __init__(self, model, num_users, num_items, embed_k, embed_d=0, feat_dim=0, feat_dtype="fp32",
                  optimizer="adam_tf23", lr=1e-3, reg=0.0, max_batch=256, device=None,
-                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False, export_item_grad=False):
+                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False, export_item_grad=False, feat_scale=448.0):
         if not torch.cuda.is_available():
             raise RuntimeError("fashionvisualexpl_recommend_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _ffi.lib()
@@ -43,12 +43,13 @@ class Engine:
         self.U, self.I, self.k = int(num_users), int(num_items), int(embed_k)
         self.d, self.D = (int(embed_d), int(feat_dim)) if model == "vbpr" else (0, 0)
         self.feat_dtype = feat_dtype
+        self.feat_scale = float(feat_scale)
         self.max_batch = int(max_batch)
         cfg = _ffi.Config(_ffi.ABI_VERSION, _ffi.MODEL[model], self.U, self.I, self.k, self.d, self.D,
                           _ffi.FEAT_DTYPE[feat_dtype], _ffi.OPTIMIZER[optimizer], self.device.index, self.max_batch,
                           lr, reg, beta1, beta2, epsilon,
                           (_ffi.FLAG_EXPORT_USER_GRAD if export_user_grad else 0) |
-                          (_ffi.FLAG_EXPORT_ITEM_GRAD if export_item_grad else 0))
+                          (_ffi.FLAG_EXPORT_ITEM_GRAD if export_item_grad else 0), self.feat_scale)
         h = C.c_void_p()
         _ffi.check(None, self.lib.bprx_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -78,9 +79,16 @@ class Engine:
             return x
         t = {"Gu": prep(Gu, (self.U, self.k)), "Gi": prep(Gi, (self.I, self.k)), "Bi": prep(Bi, (self.I,))}
         if self.model == "vbpr":
-            fdt = torch.bfloat16 if self.feat_dtype == "bf16" else torch.float32
-            t.update(Tu=prep(Tu, (self.U, self.d)), F=prep(F, (self.I, self.D), fdt), E=prep(E, (self.D, self.d)),
-                     Bp=prep(Bp, (self.D,)))
+            if self.feat_dtype == "fp8":
+                # e4m3fn codes of f * feat_scale (a float8 tensor is taken as is; anything else is quantised here,
+                # round-to-nearest-even, on the device)
+                Ft = torch.as_tensor(F)
+                if Ft.dtype != torch.float8_e4m3fn:
+                    Ft = (Ft.to(device=self.device, dtype=torch.float32) * self.feat_scale).to(torch.float8_e4m3fn)
+                Fp = Ft.to(self.device).reshape(self.I, self.D).contiguous()
+            else:
+                Fp = prep(F, (self.I, self.D), torch.bfloat16 if self.feat_dtype == "bf16" else torch.float32)
+            t.update(Tu=prep(Tu, (self.U, self.d)), F=Fp, E=prep(E, (self.D, self.d)), Bp=prep(Bp, (self.D,)))
         if self.optimizer == "adam_tf23":
             for n in PARAM_NAMES:
                 if t.get(n) is None:

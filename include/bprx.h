@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BPRX_ABI_VERSION 2
+#define BPRX_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define BPRX_API __attribute__((visibility("default")))
@@ -40,7 +40,7 @@ extern "C" {
 
 enum { BPRX_MODEL_BPRMF = 0, BPRX_MODEL_VBPR = 1 };
 enum { BPRX_OPT_SGD = 0, BPRX_OPT_ADAM_TF23 = 1 };
-enum { BPRX_F_FP32 = 0, BPRX_F_BF16 = 1 };
+enum { BPRX_F_FP32 = 0, BPRX_F_BF16 = 1, BPRX_F_FP8 = 2 };   /* FP8: OCP e4m3fn codes, see feat_scale */
 
 enum {
   BPRX_OK = 0,
@@ -70,6 +70,8 @@ typedef struct {
   float reg;             /* --reg  train_rec.py:44,69 */
   float beta1, beta2, epsilon; /* adam_tf23: 0.9, 0.999, 1e-7 (tf.optimizers.Adam defaults) */
   int32_t flags;         /* BPRX_FLAG_* */
+  float feat_scale;      /* BPRX_F_FP8: F holds e4m3fn(f * feat_scale), i.e. f ~ F / feat_scale (448 for max-abs-normalised
+                            features, visual_loader_mixin.py:30); ignored otherwise */
 } bprx_config;
 
 /* BPRX_FLAG_EXPORT_USER_GRAD (item-sharded multi-GPU, sgd only): the bound Gu/Tu are per-step STAGING rows fetched from
@@ -87,7 +89,7 @@ typedef struct {
   float *Gi;       /* [I,k]  BPRMF.py:50 */
   float *Bi;       /* [I]    BPRMF.py:48 */
   float *Tu;       /* [U,d]  VBPR.py:46  */
-  const void *F;   /* [I,D]  VBPR.py:49, frozen; fp32 or bf16 per feat_dtype */
+  const void *F;   /* [I,D]  VBPR.py:49, frozen; fp32, bf16 or fp8 (e4m3fn) per feat_dtype */
   float *E;        /* [D,d]  VBPR.py:52  */
   float *Bp;       /* [D]    VBPR.py:44 ([D,1]) */
   float *m_Gu, *v_Gu, *m_Gi, *v_Gi, *m_Bi, *v_Bi, *m_Tu, *v_Tu, *m_E, *v_E, *m_Bp, *v_Bp; /* Adam slots */

@@ -198,8 +198,11 @@ typedef struct {
   int64_t adam_t;  /* optimizer.iterations */
   /* operand rounding that mirrors the device's reduced-precision projection:
      0 = none (reference fp32 semantics)
-     1 = bf16: E|Bp rounded to bf16 in the forward product, W=(g*[theta|1]) rounded to bf16 in dE */
+     1 = bf16: E|Bp rounded to bf16 in the forward product, W=(g*[theta|1]) rounded to bf16 in dE
+     2 = fp8:  E|Bp rounded to OCP e4m3fn after scaling by qscale = 448 / max|E,Bp| (set by the caller before every
+               call; F is expected to hold already-dequantised fp8 values), W rounded to bf16 in dE */
   int32_t quant;
+  float qscale;
 } orc_model;
 
 static float bf16_round(float x) {
@@ -210,7 +213,35 @@ static float bf16_round(float x) {
 }
 float orc_bf16_round(float x) { return bf16_round(x); }
 
-static inline float qz(const orc_model *m, float x) { return m->quant == 1 ? bf16_round(x) : x; }
+/* value of the OCP e4m3fn code nearest to x (round-to-nearest-even, saturating at +-448); x finite */
+static float e4m3_round(float x) {
+  uint32_t u; memcpy(&u, &x, 4);
+  uint32_t a = u & 0x7fffffffu;
+  float ax; memcpy(&ax, &a, 4);
+  float r;
+  if (ax < 0.015625f) {                     /* below 2^-6: multiples of 2^-9 */
+    r = rintf(ax * 512.0f) * (1.0f / 512.0f);
+  } else {
+    uint32_t rr = a + 0x7ffffu + ((a >> 20) & 1u);   /* keep 3 mantissa bits, RNE */
+    int e = (int)(rr >> 23) - 127;
+    uint32_t mm = (rr >> 20) & 7u;
+    if (e > 8 || (e == 8 && mm == 7u)) r = 448.0f;
+    else { rr &= 0xfff00000u; memcpy(&r, &rr, 4); }
+  }
+  return (u >> 31) ? -r : r;
+}
+float orc_e4m3_round(float x) { return e4m3_round(x); }
+void orc_e4m3_round_array(const float *in, float *out, int64_t n) {
+  for (int64_t e = 0; e < n; e++) out[e] = e4m3_round(in[e]);
+}
+
+/* operand rounding of E|Bp in the forward projection, and of W in the dense gradient */
+static inline float qz(const orc_model *m, float x) {
+  if (m->quant == 1) return bf16_round(x);
+  if (m->quant == 2) return e4m3_round(x * m->qscale) / m->qscale;
+  return x;
+}
+static inline float qw(const orc_model *m, float x) { return m->quant ? bf16_round(x) : x; }
 
 /* P[0..d-1] = f_item . E[:,c],  P[d] = f_item . Bp      (VBPR.py:83-84) */
 static void project_item(const orc_model *m, int32_t item, float *P) {
@@ -369,7 +400,7 @@ double orc_step(orc_model *m, const int32_t *u, const int32_t *i, const int32_t 
     dE = (double *)calloc((size_t)D * d, sizeof(double));
     dBp = (double *)calloc((size_t)D, sizeof(double));
     float *Wq = (float *)malloc(sizeof(float) * (size_t)nT * d1);
-    for (size_t e = 0; e < (size_t)nT * d1; e++) Wq[e] = qz(m, (float)W[e]);
+    for (size_t e = 0; e < (size_t)nT * d1; e++) Wq[e] = qw(m, (float)W[e]);
 #pragma omp parallel for schedule(static)
     for (int r = 0; r < D; r++) {
       double acc[d1];

@@ -30,7 +30,7 @@ class _Model(C.Structure):
                 ("mGu", C.c_void_p), ("vGu", C.c_void_p), ("mGi", C.c_void_p), ("vGi", C.c_void_p),
                 ("mBi", C.c_void_p), ("vBi", C.c_void_p), ("mTu", C.c_void_p), ("vTu", C.c_void_p),
                 ("mE", C.c_void_p), ("vE", C.c_void_p), ("mBp", C.c_void_p), ("vBp", C.c_void_p),
-                ("adam_t", C.c_int64), ("quant", C.c_int32)]
+                ("adam_t", C.c_int64), ("quant", C.c_int32), ("qscale", C.c_float)]
 
 
 class _Taps(C.Structure):
@@ -59,6 +59,7 @@ def lib():
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_sample_epoch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64,
                                        C.c_uint32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_e4m3_round_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_bf16_round.restype = C.c_float
         L.orc_bf16_round.argtypes = [C.c_float]
         L.orc_num_threads.restype = C.c_int
@@ -141,6 +142,14 @@ def bf16_round(a):
     return r.view(np.float32).reshape(a.shape)
 
 
+def e4m3_round(a):
+    """Value of the nearest OCP e4m3fn code (round-to-nearest-even, saturating at +-448), elementwise."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().orc_e4m3_round_array(_p(a), _p(out), a.size)
+    return out
+
+
 class OracleModel:
     """Holds fp32 numpy tables (same shapes as the reference's tf.Variables) and steps them on the CPU."""
 
@@ -175,6 +184,10 @@ class OracleModel:
         m.F = _p(self.F)
         m.adam_t = self.adam_t
         m.quant = self.quant
+        m.qscale = 1.0
+        if self.quant == 2 and self.E is not None:            # the device's per-step scale: 448 / max|E,Bp| in fp32
+            amax = np.float32(max(np.abs(self.E).max(), np.abs(self.Bp).max()))
+            m.qscale = float(np.float32(448.0) / amax) if amax > 0 else 1.0
         return m
 
     @staticmethod
