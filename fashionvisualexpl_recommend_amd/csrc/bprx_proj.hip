@@ -635,26 +635,22 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
 // NWMIN: smallest workgroup (waves) the launcher may pick for this instantiation (fixes the B pieces per thread)
 template <int NT, int MT, int NWMIN, bool F8>
 __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const uint16_t *__restrict__ Et, uint16_t (*Bs)[NT * 16 * (KC + 16)],
-                                        f32x4 (&acc)[2][NT], int D, int cshift, int r, int q) {
+                                        f32x4 (&acc)[2][NT], int D, int cshift, int r, int q, int et_chunk) {
   constexpr int BSS = KC + 16;
   constexpr int KS = KC / 32;
   constexpr int NPIECE = NT * 16 * (KC / 8);              // 16-B pieces of one [E|Bp]^T chunk (contiguous in Et)
   constexpr int NBP = (NPIECE + NWMIN * 64 - 1) / (NWMIN * 64);   // pieces per thread for the smallest workgroup;
-  int bofs[NBP], lofs[NBP];                               // surplus slots clamp onto piece NPIECE-1 (one address per wave)
-#pragma unroll
-  for (int x = 0; x < NBP; ++x) {
-    int pc = threadIdx.x + x * (int)blockDim.x;
-    pc = pc < NPIECE ? pc : NPIECE - 1;
-    bofs[x] = pc * 8;
-    lofs[x] = (pc / (KC / 8)) * BSS + (pc % (KC / 8)) * 8;
-  }
+  // piece x of this thread: tid + x*blockDim, surplus slots clamp onto piece NPIECE-1 (one address per wave); the
+  // offsets are recomputed at every use (two VALU ops) instead of living in 2*NBP registers
+  const int tid = threadIdx.x, bdim = (int)blockDim.x;
+  auto piece = [&](int x) { const int pc = tid + x * bdim; return pc < NPIECE ? pc : NPIECE - 1; };
   const int nch = D / KC;
   auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
   i32x4 bX[NBP], bY[NBP], aX[KS][MT], aY[KS][MT];
 #define V8_ISSUE(c_, BR, AR)                                                                                          \
   {                                                                                                                   \
     const int k1 = kof(c_);                                                                                           \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_gload(BR[x], &Et[(size_t)(k1 >> 7) * (NT * 16 * 128) + bofs[x]]); \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_gload(BR[x], &Et[(size_t)(k1 >> 7) * et_chunk + piece(x) * 8]); \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
         asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
   }
@@ -662,7 +658,10 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
   {                                                                                                                   \
     asm_vmcnt<NWAIT>();                                                                                               \
     _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_tie(BR[x]);                                                   \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x) *reinterpret_cast<i32x4 *>(&Bs[buf_][lofs[x]]) = BR[x];           \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                 \
+      const int pc = piece(x);                                                                                        \
+      *reinterpret_cast<i32x4 *>(&Bs[buf_][(pc / (KC / 8)) * BSS + (pc % (KC / 8)) * 8]) = BR[x];                     \
+    }                                                                                                                 \
   }
 #define V8_COMPUTE(buf_, AR, NWAIT)                                                                                   \
   {                                                                                                                   \
@@ -682,7 +681,7 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
         asm_dsread(bfr[f + LWIN8], &Bs[buf_][(((f + LWIN8) % NT) * 16 + r) * BSS + ((f + LWIN8) / NT) * 32 + q * 8]); \
     }                                                                                                                 \
   }
-  constexpr int LWIN8 = NT <= 7 ? 8 : 4;   // LDS fragment reads in flight (register budget of the wide instantiations)
+  constexpr int LWIN8 = NT <= 6 ? 8 : 4;   // LDS fragment reads in flight (register budget of the wide instantiations)
   constexpr int NA = KS * MT, NALL = NBP + KS * MT;
   V8_ISSUE(0, bX, aX)
   V8_PARK(0, bX, NA)
@@ -714,7 +713,7 @@ template <int NT, int NWMAX, bool F8>
 __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
                                                           int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
                                                           float *__restrict__ P, int PS, int32_t *errflag, int stagger,
-                                                          const float *__restrict__ pscale, int tiles_per_wave) {
+                                                          const float *__restrict__ pscale, int tiles_per_wave, int n0) {
   __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * (KC + 16)];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -743,8 +742,11 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
-  if (nlive == 2) v8_body<NT, 2, NWMIN, F8>(arow, Et, Bs, acc, D, cshift, r, q);
-  else v8_body<NT, 1, NWMIN, F8>(arow, Et, Bs, acc, D, cshift, r, q);    // nlive == 0: a spare wave repeats a tile
+  // this launch covers the NT column tiles [n0, n0 + NT*16) of the PS-wide projection (wide projections are split
+  // over two launches): the chunk images are PS*128 elements apart, the rows of a chunk contiguous from n0*128
+  const uint16_t *Et0 = Et + (size_t)n0 * 128;
+  if (nlive == 2) v8_body<NT, 2, NWMIN, F8>(arow, Et0, Bs, acc, D, cshift, r, q, PS * 128);
+  else v8_body<NT, 1, NWMIN, F8>(arow, Et0, Bs, acc, D, cshift, r, q, PS * 128);   // nlive == 0: a spare wave repeats a tile
   const float ps = F8 ? *pscale : 1.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
       const int t = tile[mt] * 16 + q * 4 + reg;
       if (t < nrows) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + n0 + nt * 16 + r] = acc[mt][nt][reg] * ps;
       }
     }
   }
@@ -812,6 +814,38 @@ extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generat
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
 #define FWD_ARGS (const uint16_t *)h->t.F, rows, (int)nrows, h->cfg.num_items, Deq, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
 template <int NT>
+void launch_v8(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
+               const float *pscale, int stagger, int n0) {
+  constexpr int NWMAX = 8, NWMIN = 5;
+  const int64_t T = (nrows + 15) / 16;
+  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+  int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
+  if (G < ncu) G = T < ncu ? T : ncu;
+  else G = (G + ncu - 1) / ncu * ncu;
+  const int tpw_max = (int)((T + G - 1) / G);                 // most tiles any workgroup owns (<= 2 NWMAX)
+  const int per_wave = tpw_max > NWMAX ? 2 : 1;
+  int nw = (tpw_max + per_wave - 1) / per_wave;
+  if (nw < NWMIN) nw = NWMIN;
+  if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, true>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stagger, pscale, per_wave, n0);
+  else hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, false>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stagger, pscale, per_wave, n0);
+}
+
+void launch_v8_rt(int nt, bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
+                  const float *pscale, int stagger, int n0) {
+  switch (nt) {
+    case 1: launch_v8<1>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 2: launch_v8<2>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 3: launch_v8<3>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 4: launch_v8<4>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 5: launch_v8<5>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 6: launch_v8<6>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 7: launch_v8<7>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    case 8: launch_v8<8>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+    default: launch_v8<9>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
+  }
+}
+
+template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   constexpr int MTD = NT <= 9 ? 2 : 1;
   // fwd_variant: 0 = v1 (2 barriers per chunk, nothing overlapped), 1 = v1 with one row tile per wave,
@@ -841,23 +875,22 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
       }
     }
   }
-  {
-    // v == 4: v8 (one balanced workgroup per CU; 5..8 waves up to NT = 7, 4 waves with the 512-register file above)
-    constexpr int NWMAX = NT <= 9 ? 8 : 4;
-    constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
-    if (v == 4 && Deq % 256 == 0 && bprx_variant_safe(8, NT, NWMAX, f8 ? 1 : 0)) {
-      const int64_t T = (nrows + 15) / 16;
-      const int ncu = h->num_cu > 0 ? h->num_cu : 256;
-      int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
-      if (G < ncu) G = T < ncu ? T : ncu;
-      else G = (G + ncu - 1) / ncu * ncu;
-      const int tpw_max = (int)((T + G - 1) / G);                 // most tiles any workgroup owns (<= 2 NWMAX)
-      const int per_wave = tpw_max > NWMAX ? 2 : 1;
-      int nw = (tpw_max + per_wave - 1) / per_wave;
-      if (nw < NWMIN) nw = NWMIN;
-      if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, true>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, pscale, per_wave);
-      else hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, false>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stg & 1, pscale, per_wave);
-      return 0;
+  if (v == 4 && Deq % 256 == 0) {
+    // v8 (one balanced workgroup per CU).  Projections wider than 9 column tiles (d > 143) are covered by two launches
+    // over column ranges (F is read twice: still less time than one pass of the plain kernel).
+    if constexpr (NT <= 9) {
+      if (bprx_variant_safe(8, NT, 8, f8 ? 1 : 0)) { launch_v8<NT>(h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, 0); return 0; }
+    } else {
+      // two column ranges [0, na) and [NT - nb, NT) of spill-free widths (<= 9 tiles each); they may overlap by a
+      // tile, which is then computed and stored twice with identical values
+      int na = (NT + 1) / 2, nb = NT - na;
+      while (na <= 9 && !bprx_variant_safe(8, na, 8, f8 ? 1 : 0)) ++na;
+      while (nb <= 9 && !bprx_variant_safe(8, nb, 8, f8 ? 1 : 0)) ++nb;
+      if (na <= 9 && nb <= 9) {
+        launch_v8_rt(na, h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, 0);
+        launch_v8_rt(nb, h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, (NT - nb) * 16);
+        return 0;
+      }
     }
   }
   if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale);
