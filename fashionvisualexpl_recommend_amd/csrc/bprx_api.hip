@@ -22,7 +22,7 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->qs, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->cntU, h->cntI};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->cntU, h->cntI};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -105,6 +105,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     A(dalloc_zero(&h->dEp, D * d + D));
     A(dalloc_zero(&h->part, (size_t)h->SK * D * PS));
     A(dalloc_zero(&h->qs, (size_t)4));
+    if (cfg->feat_dtype != BPRX_F_FP32)   // tiled copy of F, item count padded to whole 32-item blocks
+      A(dalloc_zero((uint8_t **)&h->Ft, (size_t)((I + 31) / 32 * 32) * D * (cfg->feat_dtype == BPRX_F_FP8 ? 1 : 2)));
   }
 #undef A
   if (!ok) {
@@ -213,6 +215,10 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
   if (((uintptr_t)t->Gu | (uintptr_t)t->Gi | (uintptr_t)t->Tu | (uintptr_t)t->F | (uintptr_t)t->E) & 15)
     BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: table base pointers must be 16-byte aligned");
   h->t = *t;
+  {
+    const int rc = bprx_launch_tile_F(h);   // the projections read a tiled copy of the frozen F (made here, once)
+    if (rc) return rc;
+  }
   h->bound = true;
   return BPRX_OK;
 }

@@ -33,6 +33,7 @@ struct bprx_handle {
   float *W;                       // [I][PS]  sum_b +-g_b*[theta_u|1] per item; all-zero between steps
   void *Wb;                       // bf16 [I][PS] copy of W for the backward MFMA
   float *Ppair;                   // [max_batch][PS] projections for bprx_score_pairs
+  void *Ft;                       // tiled copy of F (bf16 / fp8 features): 8-KB blocks of 32 items x 256 B, see k_tile_F
   void *Et;                       // bf16 [PS][D]: [E|Bp|0]^T, refreshed every step
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
@@ -111,6 +112,7 @@ int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStrea
 int bprx_launch_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);
 int bprx_launch_score_gemm(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);
 // projection part (bprx_proj.hip)
+int bprx_launch_tile_F(bprx_handle *h);
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s);
 int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s);
 int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s);

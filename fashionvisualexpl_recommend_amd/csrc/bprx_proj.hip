@@ -99,6 +99,29 @@ __global__ __launch_bounds__(256) void k_cast_Et8(const float *__restrict__ E, c
 // then sit at a power-of-two stride and every workgroup's chunk load lands on the same few L2 channels.)
 __device__ __forceinline__ size_t et_idx(int n, int k, int PS) { return ((size_t)(k >> 7) * PS + n) * 128 + (k & 127); }
 
+// TILED copy of the frozen feature table (made once at bprx_bind_tables; the projections read only this copy).
+// Units: 16-bit elements (a bf16 row has D of them, an fp8 row D/2 -- "Deq").  The matrix is cut into blocks of
+// 32 items x 128 units = 8 KB, each block contiguous, blocks ordered item-block-major:
+//     unit (t, c)  ->  ((t >> 5) * (Deq / 128) + (c >> 7)) * 4096 + (t & 31) * 128 + (c & 127)
+// Why: both projections consume F in column slices (forward: 16 items x 256 B per k-chunk and wave; backward: 32 items x
+// 256-512 B per tile).  In the row-major table those slices are 64-512-B pieces 8 KB apart -- the stand-alone probe
+// (scripts/probe/ldpat.hip) streams that pattern at 4.5-5.3 TB/s, the same fragment loads inside contiguous 4-KB
+// blocks at 5.4-5.9 TB/s.  Items past the end of the table are zero rows of the last block (no bounds masks needed).
+__device__ __forceinline__ size_t ft_row(int t, int Deq) { return ((size_t)(t >> 5) * (Deq >> 7)) * 4096 + (size_t)(t & 31) * 128; }
+__device__ __forceinline__ size_t ft_col(int c) { return (size_t)(c >> 7) * 4096 + (c & 127); }
+
+__global__ __launch_bounds__(256) void k_tile_F(const uint16_t *__restrict__ F, uint16_t *__restrict__ Ft, int I, int Deq) {
+  // one workgroup per 8-KB block: 512 pieces of 16 B; piece p = row (p >> 4), 16-B column (p & 15)
+  const int cb = blockIdx.x, tb = blockIdx.y;
+  uint4 *dst = reinterpret_cast<uint4 *>(Ft + ((size_t)tb * (Deq >> 7) + cb) * 4096);
+  for (int p = threadIdx.x; p < 512; p += 256) {
+    const int t = tb * 32 + (p >> 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < I) v = *reinterpret_cast<const uint4 *>(F + (size_t)t * Deq + cb * 128 + (p & 15) * 8);
+    dst[p] = v;
+  }
+}
+
 // Et(n, k) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.  One block per (64 k-rows x 16 columns) tile, transposed
 // through LDS so that every Et row segment is written as 128 contiguous bytes.
 __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, const float *__restrict__ Bp,
@@ -149,7 +172,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
     if (t >= nrows) t = nrows - 1;                      // padding lanes re-read the last row; never stored
     int item = rows ? rows[t] : t;
     if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
+    arow[mt] = F + ft_row(item, D) + q * 8;
   }
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -172,7 +195,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
     for (int ks = 0; ks < KC; ks += 32) {
       bf16x8 a[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + ((dbg_skip_a && cc > 0) ? 0 : k0) + ks);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(arow[mt] + ft_col(((dbg_skip_a && cc > 0) ? 0 : k0) + ks));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[(nt * 16 + r) * BS_STRIDE + ks + q * 8]);
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(256) void k_proj_bwd_bf16(const uint16_t *__restric
     for (int idx = threadIdx.x; idx < BT * 16; idx += 256) {       // F tile: 32 rows x 16 chunks of 16 B
       const int tr = idx >> 4, ch = idx & 15, t = t0 + tr;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < tend) v = *reinterpret_cast<const uint4 *>(F + (size_t)t * D + m0 + ch * 8);
+      if (t < tend) v = *reinterpret_cast<const uint4 *>(F + ft_row(t, D) + ft_col(m0 + ch * 8));
       *reinterpret_cast<uint4 *>(&Fs[tr * FS_STRIDE + ch * 8]) = v;
     }
     for (int idx = threadIdx.x; idx < BT * NT * 4; idx += 256) {   // W tile: fp32 -> bf16
@@ -331,6 +354,8 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
   constexpr int FSB = MC * 2 + 32;                   // F tile row stride, bytes (== 32 mod 256)
   constexpr int WSB = WsStride3<NT>::bytes;
   constexpr int FPT = BTV * FCH / NTH;               // 16-B F pieces per thread and tile
+  constexpr int CBK = MC * ESZ / 256;                // 8-KB blocks of the tiled F per 32 tile rows
+  static_assert(CBK >= 1 && BTV % 32 == 0 && (BTV * FCH) % NTH == 0, "tile must be whole 8-KB blocks");
   constexpr int WCH = NT * 2;                        // 16-B pieces per W row
   constexpr int WPT = (BTV * WCH + NTH - 1) / NTH;
   __shared__ __attribute__((aligned(16))) unsigned char Fs[BTV * FSB];
@@ -347,6 +372,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
     bx = slot % (int)gridDim.x;
   }
   const int m0 = bx * MC;
+  const int Deq = D * ESZ / 2, m0q = m0 * ESZ / 2;   // row width / first column in 16-bit units (tiled F addressing)
   const int tbeg = by * rows_per_split;
   int tend = tbeg + rows_per_split;
   if (tend > nrows) tend = nrows;
@@ -366,12 +392,11 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
     int tile_ = (TILE);                                                                                                  \
     tile_ = tile_ < ntiles ? tile_ : ntiles - 1;                                                                         \
     const int t0 = tbeg + (descend ? (ntiles - 1 - tile_) : tile_) * BTV;                                                \
+    /* tiled F: the tile is (BTV/32) x CBK contiguous 8-KB blocks; piece p lies in block p >> 9 at 16-B slot p & 511 */ \
     _Pragma("unroll") for (int x = 0; x < FPT; ++x) {                                                                    \
-      const int idx = threadIdx.x + x * NTH, tr = idx / FCH, ch = idx % FCH;                                             \
-      int t = t0 + tr;                                                                                                   \
-      t = t < tend ? t : tend - 1;                                                                                       \
-      freg[ST][x] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(F) +                       \
-                                                     ((size_t)t * D + m0) * ESZ + ch * 16);                             \
+      const int pp = threadIdx.x + x * NTH, blk = pp >> 9;                                                               \
+      const size_t bidx = (size_t)((t0 >> 5) + blk / CBK) * (Deq >> 7) + (m0q >> 7) + blk % CBK;                         \
+      freg[ST][x] = *reinterpret_cast<const uint4 *>(F + bidx * 4096 + (size_t)(pp & 511) * 8);                          \
     }                                                                                                                    \
     _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
       int idx = threadIdx.x + x * NTH;                                                                                   \
@@ -387,7 +412,8 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
     const int tile_ = (TILE);                                                                                            \
     const int t0 = tile_ < ntiles ? tbeg + (descend ? (ntiles - 1 - tile_) : tile_) * BTV : tend;                        \
     _Pragma("unroll") for (int x = 0; x < FPT; ++x) {                                                                    \
-      const int idx = threadIdx.x + x * NTH, tr = idx / FCH, ch = idx % FCH;                                             \
+      const int pp = threadIdx.x + x * NTH, blk = pp >> 9;                                                               \
+      const int tr = (blk / CBK) * 32 + ((pp & 511) >> 4), ch = (blk % CBK) * 16 + (pp & 15);                            \
       const uint32_t mk = (t0 + tr < tend) ? 0xffffffffu : 0u;                                                           \
       uint4 v = freg[ST][x];                                                                                             \
       v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;                                                                        \
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
     if (t >= nrows) t = nrows - 1;
     int item = rows ? rows[t] : t;
     if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
+    arow[mt] = F + ft_row(item, D) + q * 8;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
   const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
@@ -547,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__r
     if (!(ABL & 1) || c_ == 0) {                                                                                      \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, (k1 & bmask) + bk, NT * 16)]);      \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_gload(AR[ks][mt], arow[mt] + (k1 & amask) + ks * 32);                                                               \
+        asm_gload(AR[ks][mt], arow[mt] + ((size_t)((k1 & amask) >> 7) << 12) + ks * 32);                                                               \
     }                                                                                                                 \
   }
 #define V6_PARK(buf_, BR, NWAIT)                                                                                      \
@@ -652,7 +678,7 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
     const int k1 = kof(c_);                                                                                           \
     _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_gload(BR[x], &Et[(size_t)(k1 >> 7) * et_chunk + piece(x) * 8]); \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_gload(AR[ks][mt], arow[mt] + k1 + ks * 32);                                                               \
+        asm_gload(AR[ks][mt], arow[mt] + ((size_t)(k1 >> 7) << 12) + ks * 32);   /* k1 % 128 == 0: ft_col(k1) + ks*32 */                                                               \
   }
 #define V8_PARK(buf_, BR, NWAIT)                                                                                      \
   {                                                                                                                   \
@@ -681,7 +707,7 @@ __device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const 
         asm_dsread(bfr[f + LWIN8], &Bs[buf_][(((f + LWIN8) % NT) * 16 + r) * BSS + ((f + LWIN8) / NT) * 32 + q * 8]); \
     }                                                                                                                 \
   }
-  constexpr int LWIN8 = NT <= 6 ? 8 : 4;   // LDS fragment reads in flight (register budget of the wide instantiations)
+  constexpr int LWIN8 = NT <= 6 ? 8 : (F8 ? 3 : 4);   // LDS fragment reads in flight (register budget of the wide instantiations)
   constexpr int NA = KS * MT, NALL = NBP + KS * MT;
   V8_ISSUE(0, bX, aX)
   V8_PARK(0, bX, NA)
@@ -731,7 +757,7 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
     if (t >= nrows) t = nrows - 1;
     int item = rows ? rows[t] : t;
     if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + (size_t)item * D + q * 8;
+    arow[mt] = F + ft_row(item, D) + q * 8;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
   const int nch = D / KC;
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NWMIN = NWMAX == 8 ? 5 : NWMAX;
+  constexpr int NWMIN = NWMAX == 8 ? (NT <= 7 ? 5 : 8) : NWMAX;   // wide tiles: always 8 waves (fewer B pieces per thread)
   // this launch covers the NT column tiles [n0, n0 + NT*16) of the PS-wide projection (wide projections are split
   // over two launches): the chunk images are PS*128 elements apart, the rows of a chunk contiguous from n0*128
   const uint16_t *Et0 = Et + (size_t)n0 * 128;
@@ -812,11 +838,11 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
 
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
-#define FWD_ARGS (const uint16_t *)h->t.F, rows, (int)nrows, h->cfg.num_items, Deq, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
+#define FWD_ARGS (const uint16_t *)h->Ft, rows, (int)nrows, h->cfg.num_items, Deq, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
 template <int NT>
 void launch_v8(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
                const float *pscale, int stagger, int n0) {
-  constexpr int NWMAX = 8, NWMIN = 5;
+  constexpr int NWMAX = 8, NWMIN = NT <= 7 ? 5 : 8;   // must match the kernel's NWMIN
   const int64_t T = (nrows + 15) / 16;
   const int ncu = h->num_cu > 0 ? h->num_cu : 256;
   int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
@@ -878,19 +904,16 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   if (v == 4 && Deq % 256 == 0) {
     // v8 (one balanced workgroup per CU).  Projections wider than 9 column tiles (d > 143) are covered by two launches
     // over column ranges (F is read twice: still less time than one pass of the plain kernel).
-    if constexpr (NT <= 9) {
-      if (bprx_variant_safe(8, NT, 8, f8 ? 1 : 0)) { launch_v8<NT>(h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, 0); return 0; }
-    } else {
-      // two column ranges [0, na) and [NT - nb, NT) of spill-free widths (<= 9 tiles each); they may overlap by a
-      // tile, which is then computed and stored twice with identical values
-      int na = (NT + 1) / 2, nb = NT - na;
-      while (na <= 9 && !bprx_variant_safe(8, na, 8, f8 ? 1 : 0)) ++na;
-      while (nb <= 9 && !bprx_variant_safe(8, nb, 8, f8 ? 1 : 0)) ++nb;
-      if (na <= 9 && nb <= 9) {
-        launch_v8_rt(na, h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, 0);
-        launch_v8_rt(nb, h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, (NT - nb) * 16);
-        return 0;
+    // Column ranges of the widest spill-free width (<= 9 tiles; normally the whole projection in one launch), the last
+    // one right-aligned: ranges may overlap by some tiles, which are then computed and stored twice, identically.
+    int wmax = NT < 9 ? NT : 9;
+    while (wmax >= 1 && !bprx_variant_safe(8, wmax, 8, f8 ? 1 : 0)) --wmax;
+    if (wmax >= (NT < 5 ? NT : 5)) {
+      for (int c0 = 0; c0 < NT; c0 += wmax) {
+        const int start = c0 + wmax <= NT ? c0 : NT - wmax;
+        launch_v8_rt(wmax, h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, start * 16);
       }
+      return 0;
     }
   }
   if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale);
@@ -915,17 +938,22 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
     if (!h->item_mode)   // k_item_seg has already written Wb (bf16) itself
       hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
     // bwd_variant & 2: 8 waves / 256 columns per workgroup (needs D % 256 == 0); bits 4-5: tiles in flight - 1
-    const bool w8 = (h->bwd_variant & 2) && D % 256 == 0;
+    const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
+    const bool w8 = ((h->bwd_variant & 2) && D % 256 == 0) || f8;   // fp8: a 256-column tile row is one 256-B block row
     const int pd = ((h->bwd_variant >> 4) & 3) + 1;
     const int xmap = (h->bwd_variant & 64) ? 0 : 1;   // +64: plain blockIdx mapping (A/B)
-    const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
     dim3 g3(D / (w8 ? 256 : 128), h->SK);
 #define BWD3_LAUNCH(BTV_, NW_, PD_)                                                                                      \
   do {                                                                                                                   \
-    if (f8) hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_, true>), g3, dim3(NW_ * 64), 0, s,                 \
-                               (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap); \
-    else hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_, false>), g3, dim3(NW_ * 64), 0, s,                   \
-                            (const uint16_t *)h->t.F, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap);  \
+    if constexpr (NW_ == 8) {                                                                                            \
+      if (f8) {                                                                                                          \
+        hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, 8, PD_, true>), g3, dim3(512), 0, s, (const uint16_t *)h->Ft,   \
+                           I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap);                             \
+        break;                                                                                                           \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_, false>), g3, dim3(NW_ * 64), 0, s,                        \
+                       (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap);        \
   } while (0)
 #define BWD3_PD(BTV_, NW_)                                        \
   switch (pd) {                                                   \
@@ -945,7 +973,7 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   int rps = (I + h->SK - 1) / h->SK;
   rps = (rps + BT - 1) / BT * BT;
   dim3 grid(D / 128, h->SK);
-  hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, (const uint16_t *)h->t.F, I, D, h->W, h->PS, h->part, rps);
+  hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, (const uint16_t *)h->Ft, I, D, h->W, h->PS, h->part, rps);
   return 0;
 }
 
@@ -971,6 +999,17 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   }
 
 }  // namespace
+
+// builds the tiled copy of F (see k_tile_F); called from bprx_bind_tables, synchronous
+int bprx_launch_tile_F(bprx_handle *h) {
+  if (h->cfg.model != BPRX_MODEL_VBPR || h->cfg.feat_dtype == BPRX_F_FP32) return BPRX_OK;
+  const int I = h->cfg.num_items, Deq = h->cfg.feat_dtype == BPRX_F_FP8 ? h->cfg.feat_dim / 2 : h->cfg.feat_dim;
+  dim3 grid((unsigned)(Deq / 128), (unsigned)((I + 31) / 32));
+  hipLaunchKernelGGL(k_tile_F, grid, dim3(256), 0, 0, (const uint16_t *)h->t.F, (uint16_t *)h->Ft, I, Deq);
+  BPRX_LAUNCH_CHECK(h, "k_tile_F");
+  BPRX_HIP(h, hipStreamSynchronize(0));
+  return BPRX_OK;
+}
 
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
   if (h->cfg.feat_dtype == BPRX_F_FP32) return BPRX_OK;

@@ -23,7 +23,8 @@ __global__ void k_pat(const char *__restrict__ p, int rows_per_wave, int reps, u
           size_t off;
           if (PAT == 0) off = (size_t)(lane & 15) * ROWB + (size_t)s * 64 + (lane >> 4) * 16;          // 16 rows x 64 B
           else if (PAT == 1) off = (size_t)((s >> 4) * 2 + (lane >> 5)) * ROWB + (size_t)(s & 15) * 512 + (lane & 31) * 16;  // 2 rows x 512 B
-          else off = (size_t)(s >> 3) * ROWB + (size_t)(s & 7) * 1024 + lane * 16;                       // 1 row x 1 KB
+          else if (PAT == 2) off = (size_t)(s >> 3) * ROWB + (size_t)(s & 7) * 1024 + lane * 16;         // 1 row x 1 KB
+          else off = (size_t)(s >> 2) * 4096 + (size_t)(lane & 15) * 256 + (size_t)(s & 3) * 64 + (lane >> 4) * 16;  // 16 rows x 64 B inside a contiguous 4-KB block (tiled F)
           v[u] = *reinterpret_cast<const uint4 *>(base + off);
         }
 #pragma unroll
@@ -84,5 +85,6 @@ int main() {
   sweep<0>(p, out, "frag16x64 ");
   sweep<1>(p, out, "rows2x512 ");
   sweep<2>(p, out, "contig1KB ");
+  sweep<3>(p, out, "frag_tiled");
   return 0;
 }
