@@ -111,7 +111,13 @@ __device__ __forceinline__ int clamp_quiet(int v, int n) { return v < 0 ? 0 : (v
 __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
                                                    const int32_t *__restrict__ neg, int64_t B, int U, int I,
                                                    int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI,
-                                                   int32_t *__restrict__ rank) {
+                                                   int32_t *__restrict__ rank, int32_t *__restrict__ seg_cursor,
+                                                   uint4 *__restrict__ zero16, size_t nzero16) {
+  // housekeeping that would otherwise be two hipMemsetAsync launches (5-6 us each on the trace): the segment cursor, and
+  // the bf16 W image of the previous step (consumed by its backward projection), re-zeroed for k_item_seg
+  if (seg_cursor && blockIdx.x == 0 && threadIdx.x == 0) *seg_cursor = 0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nzero16; e += (size_t)gridDim.x * 256)
+    zero16[e] = make_uint4(0, 0, 0, 0);
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const int u = clamp_quiet(user[b], U), i = clamp_quiet(pos[b], I), j = clamp_quiet(neg[b], I);
@@ -692,12 +698,14 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   const int G = pick_group(a.k, a.d, vec);
   if (h->fast_rows || h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
+    const bool zw = h->item_mode && a.d && h->cfg.feat_dtype != BPRX_F_FP32;      // bf16 W image: rows of untouched items
     hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI,
-                       a.fastU, a.fastI, h->item_mode ? h->seg_rank : (int32_t *)nullptr);
+                       a.fastU, a.fastI, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
+                       h->item_mode ? h->seg_cursor : (int32_t *)nullptr, (uint4 *)(zw ? h->Wb : nullptr),
+                       zw ? (size_t)a.I * a.PS * sizeof(uint16_t) / 16 : (size_t)0);
   }
   if (h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
-    BPRX_HIP(h, hipMemsetAsync(h->seg_cursor, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_seg_alloc, dim3((unsigned)((2 * B + 1023) / 1024)), dim3(1024), 0, s, i, j, B, a.I, h->seg_rank, h->cntI,
                        h->seg_ptr, h->seg_cursor);
   }
@@ -721,7 +729,7 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
   float *Wf = a.d && !bf ? h->W : nullptr;
   uint16_t *Wb = a.d && bf ? (uint16_t *)h->Wb : nullptr;
   BprxProfScope ps(h, BPRX_PHASE_ITEM_SEG, s);
-  if (Wb) BPRX_HIP(h, hipMemsetAsync(Wb, 0, (size_t)a.I * a.PS * sizeof(uint16_t), s));   // rows of untouched items
+  // (the bf16 image was re-zeroed by k_row_count: rows of untouched items stay zero)
   const dim3 grid = grid_for(2 * B, G);
 #define LAUNCH_SEG(GG)                                                                                                   \
   do {                                                                                                                   \
