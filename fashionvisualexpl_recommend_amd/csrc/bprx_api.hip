@@ -154,7 +154,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   // both are bandwidth-bound and interfere: proj_bwd 93 -> 144 us, apply 35 -> 64 us).  Off unless BPRX_SIDE_STREAM=1.
   {
     const char *e = getenv("BPRX_SIDE_STREAM");
-    if (!(e && atoi(e))) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
+    h->side_mode = e ? atoi(e) : 0;
+    if (!h->side_mode) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
   }
   {
     hipDeviceProp_t prop;
@@ -267,12 +268,21 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  h->item_mode = h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items);
+  const bool fork_index = vb && !h->proj_fresh && h->side && h->side_mode == 2;
+  if (fork_index) {                                        // index pass (no dependence on P) beside the projection
+    BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
+    BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, h->side))) return rc;
+    BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
+  }
   if (vb && !h->proj_fresh) {
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
   }
   h->proj_fresh = false;
-  h->item_mode = h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items);
+  if (fork_index) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
+  else if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, h->cfg.lr, s))) return rc;             // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
@@ -283,7 +293,7 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     float t = (float)h->adam_t;
     lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
   }
-  if (vb && h->side) {
+  if (vb && h->side && h->side_mode == 1) {
     BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
     BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, h->side))) return rc;

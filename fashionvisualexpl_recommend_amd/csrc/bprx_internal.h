@@ -56,6 +56,7 @@ struct bprx_handle {
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
   bool side_pending;
+  int side_mode;                  // BPRX_SIDE_STREAM: 1 = sparse optimizer pass beside proj_bwd, 2 = index pass beside proj_fwd
   // per-kernel HIP-event timing (bprx_profile_*)
   bool prof;
   struct ProfRec { int phase; hipEvent_t a, b; };
@@ -102,6 +103,7 @@ struct BprxProfScope {
 // sparse part (bprx_sparse.hip)
 int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_t B, const float *Prow,
                       int p_by_pair, float *x, hipStream_t s);
+int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s);
 int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
                              hipStream_t s);
 int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int64_t B, float lr_t, hipStream_t s);

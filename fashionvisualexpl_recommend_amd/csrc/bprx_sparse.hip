@@ -692,10 +692,10 @@ int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_
   return BPRX_OK;
 }
 
-int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
+// row multiplicities / ranks / segment offsets: needs only the index arrays (not P), so it may run beside the forward
+// projection (bprx_step_begin)
+int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
   SparseArgs a = make_args(h, h->P);
-  const bool vec = vec_ok(h);
-  const int G = pick_group(a.k, a.d, vec);
   if (h->fast_rows || h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
     const bool zw = h->item_mode && a.d && h->cfg.feat_dtype != BPRX_F_FP32;      // bf16 W image: rows of untouched items
@@ -709,6 +709,14 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
     hipLaunchKernelGGL(k_seg_alloc, dim3((unsigned)((2 * B + 1023) / 1024)), dim3(1024), 0, s, i, j, B, a.I, h->seg_rank, h->cntI,
                        h->seg_ptr, h->seg_cursor);
   }
+  BPRX_LAUNCH_CHECK(h, "k_row_count/k_seg_alloc");
+  return BPRX_OK;
+}
+
+int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
+  SparseArgs a = make_args(h, h->P);
+  const bool vec = vec_ok(h);
+  const int G = pick_group(a.k, a.d, vec);
   BprxProfScope ps(h, BPRX_PHASE_TRIPLET, s);
   // W (fp32) must be all-zero here.  bf16 features: k_cast_W (backward variants >= 8) re-zeroes it while converting and
   // k_item_seg re-zeroes the rows it folds in, so only the remaining combinations need the memset.
