@@ -288,6 +288,30 @@ def test_hot_items_segments_and_atomic_excess(model, opt, item_mode, monkeypatch
     e.sync_check()
 
 
+@pytest.mark.parametrize("B", [1, 3, 65, 1000])
+@pytest.mark.parametrize("model", ["bprmf", "vbpr"])
+def test_ragged_batch_sizes_with_segments_forced(model, B, monkeypatch):
+    """Occurrence segments at batch sizes that fill neither a lane group, a wave nor a workgroup (1, 3, 65) and one
+    that is no multiple of anything (1000), item count not a multiple of the 32-item feature blocks."""
+    monkeypatch.setenv("BPRX_ITEM_MODE", "2")
+    U, I, k = 37, 45, 32
+    d, D = (20, 128) if model == "vbpr" else (0, 0)
+    t = _tables(U, I, k, d, D, seed=21, bf16=(model == "vbpr"))
+    kw = dict(embed_d=d, feat_dim=D, feat_dtype="bf16") if model == "vbpr" else {}
+    e = _engine(model=model, num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=0.05, reg=1e-3, max_batch=1000, **kw).bind(**t)
+    o = orc.OracleModel(**t, quant=1 if model == "vbpr" else 0)
+    for step in range(2):
+        u, i, j = _batch(U, I, B, 90 + step)
+        loss = e.step(_dev(u), _dev(i), _dev(j)).item()
+        want = o.step(u, i, j, "sgd", 0.05, 1e-3)
+        assert loss == pytest.approx(want, rel=1e-4 if d else 2e-5)
+        rt, at = (2e-5, 2e-6) if not d else (2e-3, 1e-4)
+        for n in (("Gu", "Gi", "Bi", "Tu", "E", "Bp") if d else ("Gu", "Gi", "Bi")):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d B %d" % (n, step, B),
+                   1e-3 if d else 0.0, 5e-4 if d else 0.0)
+    e.sync_check()
+
+
 def test_device_eval_matches_reference_golden(golden_dir):
     """bprx_eval_users fed with the SAME score matrices the reference's own Evaluator was run on
     (tests/golden/gen_golden.py): per-user metrics averaged exactly like Evaluator.py:189-193, ties included."""
