@@ -85,7 +85,7 @@ def lib():
         "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
         "bprx_profile_read": (C.c_int, [vp, vp, vp]),
         "bprx_sample_philox": (C.c_int, [vp, vp, vp, i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp, vp, vp]),
-        "bprx_sample_epoch": (C.c_int, [vp, vp, vp, vp, i32, i32, C.c_uint64, u32, i64, i64, vp, vp, vp, vp]),
+        "bprx_sample_epoch": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_uint64, u32, i64, i64, vp, vp, vp, vp]),
         "bprx_sampler_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "bprx_sampler_destroy": (C.c_int, [vp]),
         "bprx_sampler_count": (i64, [vp, i32, i32]),

@@ -61,17 +61,19 @@ __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict
 // the reference's, every interaction is visited exactly once per epoch.
 __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict__ indptr, const int32_t *__restrict__ items,
                                                       const int32_t *__restrict__ perm, const int64_t *__restrict__ epoch_ptr,
-                                                      int U, uint32_t I, uint32_t k0, uint32_t k1, uint32_t epoch,
+                                                      const int32_t *__restrict__ pos_slot, int U, uint32_t I, uint32_t k0, uint32_t k1, uint32_t epoch,
                                                       long long first, long long B, int32_t *__restrict__ u,
                                                       int32_t *__restrict__ i, int32_t *__restrict__ j) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const long long n = first + b;
-  int lo = 0, hi = U;                                   // largest a with epoch_ptr[a] <= n
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (epoch_ptr[mid] <= n) lo = mid; else hi = mid;
-  }
+  int lo = 0, hi = U;                                   // largest a with epoch_ptr[a] <= n (and a non-empty list)
+  if (pos_slot) lo = pos_slot[n];                       // precomputed once per epoch
+  else
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (epoch_ptr[mid] <= n) lo = mid; else hi = mid;
+    }
   const int32_t uu = perm[lo];
   const long long l0 = indptr[uu], len = indptr[uu + 1] - l0;
   const int32_t *lst = items + l0;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
 }  // namespace
 
 extern "C" int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
-                                 const int64_t *epoch_ptr, int32_t num_users, int32_t num_items, uint64_t seed,
+                                 const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items, uint64_t seed,
                                  uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
                                  void *stream) {
   if (!indptr || !items_sorted || !perm || !epoch_ptr || !user || !pos || !neg || num_users <= 0 || num_items <= 0 ||
@@ -101,7 +103,7 @@ extern "C" int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sor
     return BPRX_E_INVALID;
   if (B == 0) return BPRX_OK;
   hipLaunchKernelGGL(k_sample_epoch, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
-                     items_sorted, perm, epoch_ptr, num_users, (uint32_t)num_items, (uint32_t)seed, (uint32_t)(seed >> 32),
+                     items_sorted, perm, epoch_ptr, pos_slot, num_users, (uint32_t)num_items, (uint32_t)seed, (uint32_t)(seed >> 32),
                      epoch, (long long)first, (long long)B, user, pos, neg);
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }

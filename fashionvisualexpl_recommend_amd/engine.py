@@ -273,6 +273,9 @@ class EpochWalkSampler(PhiloxSampler):
         lens = (self.indptr[1:] - self.indptr[:-1]).index_select(0, self.perm.long())
         self.epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
         torch.cumsum(lens, 0, out=self.epoch_ptr[1:])
+        # position -> slot of its user in the epoch order, once per epoch (4 B per interaction): saves the per-triplet
+        # binary search over epoch_ptr in the kernel
+        self.pos_slot = torch.repeat_interleave(torch.arange(U, dtype=torch.int32, device=self.device), lens)
         self.epoch, self.pos_in_epoch = epoch, 0
 
     def sample(self, B, first=None, out=None):
@@ -285,7 +288,7 @@ class EpochWalkSampler(PhiloxSampler):
         while done < B:
             n = min(B - done, self.num_pos - self.pos_in_epoch)
             rc = self.lib.bprx_sample_epoch(_ptr(self.indptr), _ptr(self.items), _ptr(self.perm), _ptr(self.epoch_ptr),
-                                            self.indptr.numel() - 1, self.num_items, self.seed, self.epoch,
+                                            _ptr(self.pos_slot), self.indptr.numel() - 1, self.num_items, self.seed, self.epoch,
                                             self.pos_in_epoch, n, _ptr(u[done:]), _ptr(i[done:]), _ptr(j[done:]), _stream())
             if rc < 0:
                 raise _ffi.BprxError(rc, "bprx_sample_epoch failed")
