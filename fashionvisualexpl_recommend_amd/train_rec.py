@@ -32,7 +32,8 @@ def parse_args(argv=None):
     parser.add_argument('--reg', type=float, default=0, help='regularization')
     # not in the reference
     parser.add_argument('--optimizer', default='adam_tf23', choices=['adam_tf23', 'sgd'])
-    parser.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help='storage type of the feature table F')
+    parser.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp8'],
+                        help='storage type of the feature table F (fp8 = OCP e4m3fn codes of f*448)')
     parser.add_argument('--init_seed', type=int, default=0)
     parser.add_argument('--data_root', default=None, help="overrides the reference's '../data'")
     parser.add_argument('--results_root', default=None, help="overrides the reference's '../results'")

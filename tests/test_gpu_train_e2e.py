@@ -70,3 +70,41 @@ def test_resume_continues_the_same_run(tmp_path, opt, lr):
                                    err_msg=n)
     for key in ("hr_t", "ndcg_t", "auc_t"):
         assert abs(res[4][key] - res_full[4][key]) <= 1e-3
+
+
+@pytest.mark.parametrize("dtype,quant", [("fp32", 0), ("bf16", 1), ("fp8", 2)])
+def test_vbpr_from_feature_file_metric_parity(tmp_path, dtype, quant):
+    """VBPR end to end through the reference's surface: cnn_features_{model}_{layer}.npy (fp64) ->
+    global max-abs normalisation (visual_loader_mixin.py:22-31) -> resident fp32 / bf16 / fp8 table -> train() on the
+    reference index stream, against the CPU oracle fed with the same (quantised) table and the same stream.
+    HR@10 / NDCG@10 within 1e-3 for the fp32 table (north_star); for bf16 / fp8 the oracle rounds the same operands, but
+    rounding-boundary flips accumulate over 200+ steps: within 2e-2, stated here."""
+    from fashionvisualexpl_recommend_amd.dataset import DataLoader
+    from fashionvisualexpl_recommend_amd.models import VBPR
+    U, I, D = 300, 400, 256
+    tr, va, te = synth.make_interactions_clustered(U, I, per_user=14, clusters=10, p_in=0.9, seed=11)
+    rs = np.random.RandomState(3)
+    item_cluster = rs.randint(10, size=I)
+    feats = (np.abs(rs.standard_normal((I, D))) * (rs.rand(I, D) < 0.5) * 3.7).astype(np.float64)   # un-normalised
+    synth.write_dataset(str(tmp_path), "v1", tr, va, te, I, features=feats)
+    configs.set_roots(str(tmp_path), str(tmp_path / "results"))
+    params = Namespace(dataset="v1", validation=True, batch_size=128, epochs=3, batch_eval=128, embed_k=16, embed_d=12,
+                       lr=0.05, reg=1e-3, top_k=10, verbose=-1, restore_epochs=1, rec="vbpr", best_metric="ndcg",
+                       optimizer="sgd", init_seed=0, dtype=dtype, cnn_model="vgg19", output_layer="fc2")
+    data = DataLoader(params)
+    model = VBPR(data, params)
+    init = {n: v.cpu().numpy().copy() for n, v in model.engine.params().items()}
+    F = model.engine.t["F"].float().cpu().numpy()
+    if dtype == "fp8":
+        F = F / np.float32(448.0)
+    norm = (feats / np.abs(feats).max()).astype(np.float32)
+    assert np.abs(F - norm).max() <= {"fp32": 0.0, "bf16": 2.0 ** -8, "fp8": 2.0 ** -4}[dtype]      # the ingestion itself
+    results = model.train()
+    o = orc.OracleModel(F=F, quant=quant, **init)
+    u, i, j = orc.sample_ref_stream(tr, I, 128, 3)
+    for s in range(0, len(u), 128):
+        o.step(u[s:s + 128], i[s:s + 128], j[s:s + 128], "sgd", 0.05, 1e-3)
+    want = orc.evaluate(o.predict_all(), tr, va, te, 10)
+    tol = 1e-3 if dtype == "fp32" else 2e-2
+    for key in ("hr_v", "ndcg_v", "hr_t", "ndcg_t"):
+        assert abs(results[3][key] - want[key]) <= tol, (key, results[3][key], want[key])
