@@ -53,6 +53,9 @@ def parse():
                          "epoch-walk sampler (the reference's visiting order: user-grouped batches); pregen: resident "
                          "pre-generated index batches")
     ap.add_argument("--pos-per-user", type=int, default=20)
+    ap.add_argument("--dist-mode", default="replicated", choices=["replicated", "a2a"],
+                    help="N > 1, VBPR: replicated = user tables on every rank, one all-gather per step (default); "
+                         "a2a = user tables range-partitioned, rows fetched / gradients returned by all-to-all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-overlap", action="store_true",
                     help="draw each batch one step ahead on a side stream (measured on C2: 0.287 vs 0.280 ms/step without "
@@ -122,6 +125,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # BPRX_BENCH_FORCE_SHARDED=1 (never set by the driver): run the N > 1 code path with a single rank over RCCL, to
+    # measure what the sharded step costs besides the wire time (routing, host sync, staging copies)
+    force_sharded = world == 1 and os.environ.get("BPRX_BENCH_FORCE_SHARDED") == "1"
+    if force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         if rehearse:
             dist.init_process_group(backend="gloo")
@@ -143,7 +153,7 @@ def main():
     # user-sharded BPRMF -> local users, global items
     samp_users = users_total if w["model"] == "vbpr" else w["U"]
     samp_items = w["I"] if w["model"] == "vbpr" else w["I"] * world
-    if world > 1 and w["model"] == "vbpr":
+    if (world > 1 or force_sharded) and w["model"] == "vbpr":
         for n in ("E", "Bp"):
             if rehearse:
                 hcopy = tables[n].cpu()
@@ -153,12 +163,25 @@ def main():
                 dist.broadcast(tables[n], src=0)
         if args.optimizer != "sgd":
             raise SystemExit("multi-GPU bench supports --optimizer sgd")
-        from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
-        sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
-                                  tables["F"], tables["E"], tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B,
-                                  feat_dtype=w["dtype"], device=local_rank)
+        if args.dist_mode == "replicated":
+            # users replicated on every rank (identical initial values: one generator seed for all ranks), items / F
+            # sharded; ONE fixed-size all-gather per step (dist.ReplicatedUserVBPR)
+            from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR
+            gg = torch.Generator(device=device)
+            gg.manual_seed(4242)
+            glo = lambda r, c: (torch.rand((r, c), generator=gg, device=device) * 2 - 1) * (6.0 / (r + c)) ** 0.5
+            Gu_all, Tu_all = glo(users_total, w["k"]), glo(users_total, w["d"])
+            cap = B if args.sampler != "epoch" else B // args.pos_per_user + 256
+            sharded = ReplicatedUserVBPR(rank, world, Gu_all, Tu_all, tables["Gi"], tables["Bi"], tables["F"], tables["E"],
+                                         tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B, user_cap=cap, feat_dtype=w["dtype"],
+                                         device=local_rank)
+        else:
+            from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
+            sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
+                                      tables["F"], tables["E"], tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B,
+                                      feat_dtype=w["dtype"], device=local_rank)
         eng = sharded.eng
-    elif world > 1:
+    elif world > 1 or force_sharded:
         # user-sharded BPRMF (configs[2]): user rows stay local, item rows are exchanged by all-to-all, no all-reduce
         if args.optimizer != "sgd":
             raise SystemExit("multi-GPU bench supports --optimizer sgd")
@@ -293,8 +316,10 @@ def main():
             "config": {"workload": "%s: %s k=%d d=%d D=%d, %d users x %d items per GPU, %s features, B=%d per GPU, %s"
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
                                       w["dtype"], B, args.optimizer),
-                       "global_batch": B * world, "parallelism": "single" if world == 1 else
-                       (("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world)
+                       "global_batch": B * world, "parallelism": "single" if (world == 1 and sharded is None) else
+                       ((("item-shard x%d, users replicated: one all-gather per step (distinct users' gradient rows + "
+                          "dE|dBp), local negatives" % world) if args.dist_mode == "replicated" else
+                         ("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world))
                         if w["model"] == "vbpr" else ("user-shard x%d: all-to-all item rows, no all-reduce" % world)),
                        "sampler": (("device philox, uniform positive + rejection negative" if args.sampler == "philox" else
                                     "device epoch walk (every positive once per epoch, user-grouped) + philox negative")

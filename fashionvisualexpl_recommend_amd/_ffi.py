@@ -85,6 +85,9 @@ def lib():
         "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
         "bprx_profile_read": (C.c_int, [vp, vp, vp]),
         "bprx_sample_philox": (C.c_int, [vp, vp, vp, i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp, vp, vp]),
+        "bprx_user_msg_floats": (C.c_int64, [vp, i64]),
+        "bprx_pack_user_msg": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+        "bprx_apply_user_msgs": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
         "bprx_sample_epoch": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_uint64, u32, i64, i64, vp, vp, vp, vp]),
         "bprx_sampler_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "bprx_sampler_destroy": (C.c_int, [vp]),
@@ -104,7 +107,8 @@ EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_sync_check", "bprx_profile_enable",
-           "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_sampler_create",
+           "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",
+           "bprx_apply_user_msgs", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]
 
 

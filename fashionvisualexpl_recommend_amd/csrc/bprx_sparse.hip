@@ -682,6 +682,108 @@ extern "C" int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 
+// ---- replicated-user multi-GPU step: message packing / application (include/bprx.h) ----
+namespace {
+// msg (4-byte words): [0] count | [1, 1+cap) ids | cap*k dGu rows | cap*d dTu rows | D*d + D dense gradient
+__global__ __launch_bounds__(256) void k_pack_user_msg(const int32_t *__restrict__ user, int64_t B, int U, int k, int d,
+                                                       int cap, uint32_t *__restrict__ flagU, float *__restrict__ dGu,
+                                                       float *__restrict__ dTu, float *__restrict__ msg,
+                                                       int32_t *__restrict__ errflag) {
+  constexpr int G = 16;
+  const int64_t b = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (b >= B) return;
+  const int u = clamp_quiet(user[b], U);
+  unsigned claimed = 0;
+  int slot = 0;
+  if (lane == 0) {
+    claimed = atomicExch(flagU + u, 0u);                    // the first occurrence of a touched user owns its row
+    if (claimed) slot = atomicAdd(reinterpret_cast<int32_t *>(msg), 1);
+  }
+  claimed = __shfl(claimed, 0, G);
+  slot = __shfl(slot, 0, G);
+  if (!claimed) return;
+  float *gr = dGu + (size_t)u * k, *gt = d ? dTu + (size_t)u * d : nullptr;
+  if (slot < cap) {
+    if (lane == 0) reinterpret_cast<int32_t *>(msg)[1 + slot] = u;
+    float *og = msg + 1 + cap + (size_t)slot * k, *ot = msg + 1 + cap + (size_t)cap * k + (size_t)slot * d;
+    for (int c = lane; c < k; c += G) { og[c] = gr[c]; gr[c] = 0.f; }
+    for (int c = lane; c < d; c += G) { ot[c] = gt[c]; gt[c] = 0.f; }
+  } else {                                                  // more distinct users than the message holds: reported
+    if (lane == 0) *errflag = 4;
+    for (int c = lane; c < k; c += G) gr[c] = 0.f;
+    for (int c = lane; c < d; c += G) gt[c] = 0.f;
+  }
+}
+
+// one rank's rows: ids are distinct within a message -> plain read-modify-write
+__global__ __launch_bounds__(256) void k_apply_user_msg(const float *__restrict__ msg, int cap, int U, int k, int d,
+                                                        float *__restrict__ Gu, float *__restrict__ Tu, float scale) {
+  constexpr int G = 16;
+  const int slot = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) / G), lane = threadIdx.x % G;
+  int cnt = reinterpret_cast<const int32_t *>(msg)[0];
+  cnt = cnt < cap ? cnt : cap;
+  if (slot >= cnt) return;
+  const int u = reinterpret_cast<const int32_t *>(msg)[1 + slot];
+  if ((unsigned)u >= (unsigned)U) return;
+  const float *ig = msg + 1 + cap + (size_t)slot * k, *it = msg + 1 + cap + (size_t)cap * k + (size_t)slot * d;
+  float *pg = Gu + (size_t)u * k, *pt = d ? Tu + (size_t)u * d : nullptr;
+  for (int c = lane; c < k; c += G) pg[c] += scale * ig[c];
+  for (int c = lane; c < d; c += G) pt[c] += scale * it[c];
+}
+
+// dEp = sum over ranks (fixed order) of the dense parts of their messages
+__global__ __launch_bounds__(256) void k_sum_dense_msgs(const float *__restrict__ msgs, int nranks, size_t stride, size_t off,
+                                                        size_t n, float *__restrict__ dEp) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int r = 0; r < nranks; ++r) s += msgs[(size_t)r * stride + off + e];
+    dEp[e] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap) {
+  if (!h || cap <= 0) return -1;
+  const int64_t k = h->cfg.embed_k, d = h->cfg.embed_d, D = h->cfg.feat_dim;
+  return 1 + cap + cap * (k + d) + D * d + D;
+}
+
+extern "C" int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream) {
+  if (!h || !user || !msg || B <= 0 || cap <= 0) return BPRX_E_INVALID;
+  if (!(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD)) BPRX_FAIL(h, BPRX_E_STATE, "pack_user_msg needs BPRX_FLAG_EXPORT_USER_GRAD");
+  hipStream_t s = (hipStream_t)stream;
+  const int k = h->cfg.embed_k, d = h->cfg.embed_d;
+  BPRX_HIP(h, hipMemsetAsync(msg, 0, sizeof(float), s));                       // count
+  hipLaunchKernelGGL(k_pack_user_msg, dim3((unsigned)((B * 16 + 255) / 256)), dim3(256), 0, s, user, B, h->cfg.num_users, k, d,
+                     (int)cap, h->flagU, h->dGu, h->dTu, msg, h->errflag);
+  BPRX_LAUNCH_CHECK(h, "k_pack_user_msg");
+  const size_t nd = (size_t)h->cfg.feat_dim * (d + 1);
+  if (nd) BPRX_HIP(h, hipMemcpyAsync(msg + 1 + cap + cap * (int64_t)(k + d), h->dEp, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return BPRX_OK;
+}
+
+extern "C" int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t nranks, int64_t cap, float scale, void *stream) {
+  if (!h || !msgs || nranks <= 0 || cap <= 0) return BPRX_E_INVALID;
+  if (!h->bound) BPRX_FAIL(h, BPRX_E_STATE, "tables not bound");
+  hipStream_t s = (hipStream_t)stream;
+  const int k = h->cfg.embed_k, d = h->cfg.embed_d;
+  const size_t stride = (size_t)bprx_user_msg_floats(h, cap);
+  for (int r = 0; r < nranks; ++r)                                             // rank order: identical on every replica
+    hipLaunchKernelGGL(k_apply_user_msg, dim3((unsigned)((cap * 16 + 255) / 256)), dim3(256), 0, s, msgs + (size_t)r * stride,
+                       (int)cap, h->cfg.num_users, k, d, h->t.Gu, h->t.Tu, scale);
+  const size_t nd = (size_t)h->cfg.feat_dim * (d + 1);
+  if (nd) {
+    unsigned blocks = (unsigned)((nd + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_sum_dense_msgs, dim3(blocks), dim3(256), 0, s, msgs, nranks, stride, (size_t)(1 + cap + cap * (int64_t)(k + d)),
+                       nd, h->dEp);
+  }
+  BPRX_LAUNCH_CHECK(h, "k_apply_user_msg");
+  return BPRX_OK;
+}
+
 int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_t B, const float *Prow, int p_by_pair,
                       float *x, hipStream_t s) {
   SparseArgs a = make_args(h, h->cfg.embed_d ? (p_by_pair ? Prow : h->P) : nullptr);

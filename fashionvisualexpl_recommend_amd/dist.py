@@ -138,6 +138,58 @@ class ItemShardedVBPR:
         return loss
 
 
+class ReplicatedUserVBPR:
+    """Item-sharded VBPR with REPLICATED user tables (SURVEY 8(e), C4 option "users replicated + sparse delta
+    all-gather"): rank r owns an item shard (Gi, Bi, F never cross xGMI; negatives are local) and a full copy of Gu / Tu.
+    A step:  bprx_step_begin on the local batch (global user ids; user gradients are summed per user into the staging
+    tables instead of being applied) -> bprx_pack_user_msg: one fixed-size message per rank
+    [count | ids | dGu rows | dTu rows | dE|dBp] -> ONE all_gather_into_tensor -> bprx_apply_user_msgs: every replica adds
+    every rank's rows in rank order (bit-identical replicas) and sums the dE|dBp parts in rank order -> bprx_step_end.
+    No data-dependent split sizes, hence no host synchronisation and no all-to-all; the message holds `user_cap` distinct
+    users per batch (epoch-walk batches of B triplets touch about B / positives-per-user of them; more than user_cap is
+    reported by sync_check()).  The global step equals the single-GPU batch-synchronous step on the concatenation of all
+    ranks' batches (tests/test_gpu_dist.py).  sgd only."""
+
+    def __init__(self, rank, world, Gu, Tu, Gi_shard, Bi_shard, F_shard, E, Bp, lr, reg, max_batch, user_cap=None,
+                 feat_dtype="bf16", group=None, device=None):
+        from .engine import Engine
+        self.rank, self.world, self.group, self.lr = rank, world, group, lr
+        k, d = Gu.shape[1], Tu.shape[1]
+        self.eng = Engine(model="vbpr", num_users=Gu.shape[0], num_items=Gi_shard.shape[0], embed_k=k, embed_d=d,
+                          feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer="sgd", lr=lr, reg=reg,
+                          max_batch=max_batch, device=device, export_user_grad=True)
+        self.eng.bind(Gu=Gu, Gi=Gi_shard, Bi=Bi_shard, Tu=Tu, F=F_shard, E=E, Bp=Bp)
+        dev = self.eng.device
+        self.cap = int(user_cap if user_cap is not None else max_batch)
+        n = self.eng.user_msg_floats(self.cap)
+        self.msg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.msgs = torch.zeros(world * n, dtype=torch.float32, device=dev)
+        self.host_staged = world > 1 and dist.get_backend(group) != "nccl"     # gloo: test mode
+
+    @property
+    def Gu(self):
+        return self.eng.t["Gu"]
+
+    @property
+    def Tu(self):
+        return self.eng.t["Tu"]
+
+    def step(self, u_global, i_local, j_local, want_loss=False):
+        self.eng.step_begin(u_global, i_local, j_local)
+        self.eng.pack_user_msg(u_global, self.cap, self.msg)
+        if self.world == 1 and not dist.is_initialized():
+            self.msgs.copy_(self.msg)
+        elif self.host_staged:
+            h = self.msg.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.group)
+            self.msgs.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(self.msgs, self.msg, group=self.group)     # RCCL, the step's only collective
+        self.eng.apply_user_msgs(self.msgs, self.world, self.cap, -self.lr)
+        return self.eng.step_end(want_loss=want_loss)
+
+
 RowExchange = UserRowExchange      # the routing is the same whichever table is the remote one
 
 

@@ -159,6 +159,16 @@ class Engine:
             self._ugrad = (g, t)
         return self._ugrad
 
+    # ---- replicated-user multi-GPU step (include/bprx.h: bprx_pack_user_msg / bprx_apply_user_msgs) -------------
+    def user_msg_floats(self, cap):
+        return int(self.lib.bprx_user_msg_floats(self.h, int(cap)))
+
+    def pack_user_msg(self, user, cap, msg):
+        _ffi.check(self.h, self.lib.bprx_pack_user_msg(self.h, _ptr(user), user.numel(), int(cap), _ptr(msg), _stream()))
+
+    def apply_user_msgs(self, msgs, nranks, cap, scale):
+        _ffi.check(self.h, self.lib.bprx_apply_user_msgs(self.h, _ptr(msgs), int(nranks), int(cap), float(scale), _stream()))
+
     def item_grad(self):
         """Zero-copy views [I,k], [I] of the staging tables that hold the exported item-row gradients."""
         if getattr(self, "_igrad", None) is None:

@@ -134,6 +134,22 @@ BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
 BPRX_API int bprx_step_project(bprx_handle *h, void *stream);
 BPRX_API int bprx_user_grad(bprx_handle *h, float **dGu, float **dTu);
 BPRX_API int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream);
+/* Replicated-user multi-GPU step (item-sharded VBPR with every rank holding ALL user rows; needs
+   BPRX_FLAG_EXPORT_USER_GRAD and a handle created with num_users = the GLOBAL user count): ONE fixed-size all-gather per
+   step, no data-dependent routing, no host synchronisation.
+     bprx_user_msg_floats   size (in 4-byte words) of one rank's message for `cap` distinct users per batch
+     bprx_pack_user_msg     after bprx_step_begin: moves the summed gradient rows of the batch's distinct users out of the
+                            staging tables (which are left all-zero) into msg = [count | ids[cap] | dGu[cap,k] |
+                            dTu[cap,d] | dE|dBp], more than `cap` distinct users are reported by bprx_sync_check
+                            (BPRX_E_RANGE)
+     bprx_apply_user_msgs   after the all-gather (msgs = nranks messages back to back): Gu/Tu[id] += scale * row for
+                            every rank's rows, rank by rank in rank order (within a rank ids are distinct: plain
+                            read-modify-write, so every replica performs the same additions in the same order and the
+                            replicas stay bit-identical), and bprx_dense_grad() = sum over ranks of their dE|dBp parts in
+                            rank order; then bprx_step_end. */
+BPRX_API int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap);
+BPRX_API int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream);
+BPRX_API int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t nranks, int64_t cap, float scale, void *stream);
 BPRX_API int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi);
 BPRX_API int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, void *stream);
 BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,

@@ -125,3 +125,86 @@ def _worker_bprmf(rank, world, port):
 
 def test_user_sharded_bprmf_two_ranks_match_oracle():
     mp.spawn(_worker_bprmf, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_replicated(rank, world, port, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fashionvisualexpl_recommend_amd import synth
+        from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        U, I, k, d, D, B, lr, reg = 45, 64, 8, 20, 256, 96, 0.05, 1e-3
+        ish = I // world
+        rs = np.random.RandomState(1)
+        F = synth.make_features(I, D, seed=1)
+        F = (F / np.abs(F).max()).astype(np.float32)
+        if dtype == "bf16":
+            F = orc.bf16_round(F)
+        t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k),
+                 Bi=(rs.standard_normal(I) * 0.01).astype(np.float32), Tu=synth.glorot_uniform(rs, U, d), F=F,
+                 E=synth.glorot_uniform(rs, D, d), Bp=synth.glorot_uniform(rs, D, 1).reshape(-1))
+        it = slice(rank * ish, (rank + 1) * ish)
+        c = lambda a: torch.as_tensor(a.copy())
+        m = ReplicatedUserVBPR(rank, world, c(t["Gu"]), c(t["Tu"]), c(t["Gi"][it]), c(t["Bi"][it]), c(t["F"][it]), c(t["E"]),
+                               c(t["Bp"]), lr, reg, max_batch=B, user_cap=U, feat_dtype=dtype, device=0)
+        o = orc.OracleModel(**t, quant=1 if dtype == "bf16" else 0)
+        for step in range(3):
+            batches = []
+            for r in range(world):
+                br = np.random.RandomState(300 + step * world + r)
+                nb = B - 10 * r                           # ragged
+                batches.append((br.randint(U, size=nb).astype(np.int32), br.randint(ish, size=nb).astype(np.int32),
+                                br.randint(ish, size=nb).astype(np.int32)))
+            u, i, j = batches[rank]
+            dev = lambda a: torch.as_tensor(a, device="cuda")
+            m.step(dev(u), dev(i), dev(j))
+            o.step(np.concatenate([b[0] for b in batches]), np.concatenate([b[1] + r * ish for r, b in enumerate(batches)]),
+                   np.concatenate([b[2] + r * ish for r, b in enumerate(batches)]), "sgd", lr, reg)
+        m.eng.sync_check()
+        rt, at = (2e-5, 2e-6) if dtype == "fp32" else (2e-3, 1e-4)
+        chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=rt, atol=at, err_msg=n)
+        chk(m.Gu, o.Gu, "Gu (replicated)")
+        chk(m.Tu, o.Tu, "Tu (replicated)")
+        chk(m.eng.t["Gi"], o.Gi[it], "Gi shard")
+        chk(m.eng.t["Bi"], o.Bi[it], "Bi shard")
+        chk(m.eng.t["E"], o.E, "E (replicated)")
+        chk(m.eng.t["Bp"], o.Bp, "Bp (replicated)")
+        # every replicated table must agree BIT-exactly across ranks (same additions in the same order everywhere)
+        for n in ("Gu", "Tu", "E", "Bp"):
+            mine = m.eng.t[n].cpu()
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            assert all(torch.equal(parts[0], x) for x in parts), n
+        # the staging tables are left all-zero for the next step
+        g, tt = m.eng.user_grad()
+        assert float(g.abs().max()) == 0.0 and float(tt.abs().max()) == 0.0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_replicated_user_vbpr_two_ranks_match_oracle(dtype):
+    mp.spawn(_worker_replicated, args=(2, _free_port(), dtype), nprocs=2, join=True)
+
+
+def test_replicated_user_message_overflow_is_reported():
+    """More distinct users in a batch than the message holds: reported by sync_check, never a fault."""
+    from fashionvisualexpl_recommend_amd import _ffi, synth
+    from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR
+    rs = np.random.RandomState(5)
+    U, I, k, d, D, B = 40, 32, 8, 4, 128, 64
+    F = synth.make_features(I, D, seed=2)
+    F = (F / np.abs(F).max()).astype(np.float32)
+    c = torch.as_tensor
+    m = ReplicatedUserVBPR(0, 1, c(synth.glorot_uniform(rs, U, k)), c(synth.glorot_uniform(rs, U, d)),
+                           c(synth.glorot_uniform(rs, I, k)), c(np.zeros(I, np.float32)), c(F), c(synth.glorot_uniform(rs, D, d)),
+                           c(synth.glorot_uniform(rs, D, 1).reshape(-1)), 0.05, 0.0, max_batch=B, user_cap=8, feat_dtype="fp32",
+                           device=0)
+    u = torch.arange(B, dtype=torch.int32, device="cuda") % U
+    i = torch.arange(B, dtype=torch.int32, device="cuda") % I
+    m.step(u, i, (i + 1) % I)
+    with pytest.raises(_ffi.BprxError) as ei:
+        m.eng.sync_check()
+    assert ei.value.code == _ffi.E_RANGE
