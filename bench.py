@@ -252,14 +252,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(W):
-        one_step(s)
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(K):
-        one_step(W + s)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the loop runs on a non-default stream (BPRX_GRAPH=1 lets libbprx replay the sgd step as one hipGraph there; the
+    # legacy default stream cannot be captured -- measured slower than plain launches, so it is off by default)
+    run_stream = torch.cuda.Stream(device=device)
+    run_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(run_stream):
+        for s in range(W):
+            one_step(s)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(K):
+            one_step(W + s)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    torch.cuda.current_stream().wait_stream(run_stream)
     if world > 1:
         tmax = torch.tensor([elapsed], device="cpu" if rehearse else device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -20,6 +20,10 @@ static hipError_t dalloc_zero(T **p, size_t n) {
   return hipMemset(*p, 0, n * sizeof(T));
 }
 
+static void graph_drop(bprx_handle *h) {
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+}
+
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
                   h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->cntU, h->cntI};
@@ -161,6 +165,11 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     hipDeviceProp_t prop;
     h->num_cu = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256;
   }
+  // Measured on C2 (ROCm 7.0, bench.py on a non-default stream): replaying the step as a hipGraph is SLOWER than the
+  // eleven plain launches it replaces (0.2828 vs 0.2747 ms/step, identical results) -- the host is not the limiter
+  // and the graph launch itself costs more than the dispatch gaps it removes.  Opt-in: BPRX_GRAPH=1.
+  h->graph_mode = 0;
+  if (const char *e = getenv("BPRX_GRAPH")) h->graph_mode = atoi(e) ? 1 : 0;
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
   *out = h;
@@ -172,6 +181,7 @@ extern "C" int bprx_destroy(bprx_handle *h) {
   if (!h) return BPRX_OK;
   (void)hipSetDevice(h->cfg.device);
   free_scratch(h);
+  graph_drop(h);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -216,6 +226,7 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
   if (((uintptr_t)t->Gu | (uintptr_t)t->Gi | (uintptr_t)t->Tu | (uintptr_t)t->F | (uintptr_t)t->E) & 15)
     BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: table base pointers must be 16-byte aligned");
   h->t = *t;
+  graph_drop(h);                            // a captured step holds the old table pointers
   {
     const int rc = bprx_launch_tile_F(h);   // the projections read a tiled copy of the frozen F (made here, once)
     if (rc) return rc;
@@ -379,14 +390,64 @@ extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
   return BPRX_OK;
 }
 
-extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
-                         float *loss_out, void *stream) {
-  if (!h) return BPRX_E_INVALID;
+static int step_plain(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, float *loss_out,
+                      void *stream) {
   h->fused_reduce = true;          // no all-reduce in between: the dense update sums the split-K slabs itself
   int rc = bprx_step_begin(h, user, pos, neg, B, stream);
   if (!rc) rc = bprx_step_end(h, loss_out, stream);
   h->fused_reduce = false;
   return rc;
+}
+
+extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
+                         float *loss_out, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  // (BPRX_GRAPH=1) The sgd step is a fixed sequence of ~11 launches whose arguments repeat from call to call (index
+  // buffers, loss scalar, stream): it can be captured into a hipGraph once and replayed -- one launch per step.  Not for adam (lr_t changes every step), not while per-kernel profiling is
+  // on, not on the legacy default stream (cannot be captured): those take the plain path.
+  const bool can_graph = h->graph_mode && h->cfg.optimizer == BPRX_OPT_SGD && !h->prof && stream != nullptr && !h->side &&
+                         h->bound && B > 0 && B <= h->cfg.max_batch && user && pos && neg && !h->proj_fresh && !h->pending_B;
+  if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const bool same = h->graph_exec && h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg &&
+                    h->graph_key.loss == loss_out && h->graph_key.B == B && h->graph_key.stream == stream &&
+                    h->graph_key.lr == h->cfg.lr && h->graph_key.reg == h->cfg.reg;
+  if (!same) {
+    graph_drop(h);
+    // capture only when a call repeats the previous call's arguments (a caller that walks through a pre-generated
+    // stream passes new pointers every step and must not pay for a capture each time)
+    const bool repeat = h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg && h->graph_key.loss == loss_out &&
+                        h->graph_key.B == B && h->graph_key.stream == stream && h->graph_key.lr == h->cfg.lr &&
+                        h->graph_key.reg == h->cfg.reg;
+    h->graph_key.u = user; h->graph_key.i = pos; h->graph_key.j = neg; h->graph_key.loss = loss_out; h->graph_key.B = B;
+    h->graph_key.stream = stream; h->graph_key.lr = h->cfg.lr; h->graph_key.reg = h->cfg.reg;
+    if (!repeat) return step_plain(h, user, pos, neg, B, loss_out, stream);
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      h->graph_mode = 0;                                      // this stream cannot be captured: plain launches from now on
+      return step_plain(h, user, pos, neg, B, loss_out, stream);
+    }
+    const int rc = step_plain(h, user, pos, neg, B, loss_out, stream);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc || e != hipSuccess || !g) {
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
+      h->graph_mode = 0;
+      return rc ? rc : step_plain(h, user, pos, neg, B, loss_out, stream);
+    }
+    const hipError_t ei = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) {
+      h->graph_exec = nullptr;
+      h->graph_mode = 0;
+      return step_plain(h, user, pos, neg, B, loss_out, stream);
+    }
+    h->graph_key.u = user; h->graph_key.i = pos; h->graph_key.j = neg; h->graph_key.loss = loss_out; h->graph_key.B = B;
+    h->graph_key.stream = stream; h->graph_key.lr = h->cfg.lr; h->graph_key.reg = h->cfg.reg;
+  }
+  BPRX_HIP(h, hipGraphLaunch(h->graph_exec, s));
+  return BPRX_OK;
 }
 
 extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream) {

@@ -57,6 +57,10 @@ struct bprx_handle {
   hipEvent_t ev_fork, ev_join;
   bool side_pending;
   int side_mode;                  // BPRX_SIDE_STREAM: 1 = sparse optimizer pass beside proj_bwd, 2 = index pass beside proj_fwd
+  // hipGraph of the whole sgd step (bprx_step): captured on first use, replayed while the call's arguments repeat
+  int graph_mode;                 // env BPRX_GRAPH (default 0: measured slower than plain launches); 1 = capture + replay
+  hipGraphExec_t graph_exec;
+  struct { const void *u, *i, *j, *loss; int64_t B; void *stream; float lr, reg; } graph_key;
   // per-kernel HIP-event timing (bprx_profile_*)
   bool prof;
   struct ProfRec { int phase; hipEvent_t a, b; };
