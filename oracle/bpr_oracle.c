@@ -19,6 +19,10 @@
  *     tests or golden vectors.  Restated from source text
  *     (BPRMF.py:55-125, VBPR.py:59-144) and cross-checked against torch-CPU
  *     autograd (tests/test_oracle_step.py), a neutral check, not the reference.
+ *   - quant = 1 / 2 (bf16 / fp8 operand rounding): twins of the DEVICE's reduced-precision projections, not reference
+ *     semantics (the reference is fp32 throughout).  The e4m3 rounding is cross-checked against torch's CPU
+ *     float8_e4m3fn cast (identical on 2e5 random values inside the finite range; saturation instead of NaN beyond).
+ *   - device samplers' twins (orc_sample_philox, orc_sample_epoch): definitions of this build, no reference counterpart.
  *
  * Conventions: all parameters are fp32 row-major exactly like the reference's
  * tf.Variables; long sums are accumulated in double and rounded once to fp32 so
