@@ -139,3 +139,22 @@ def test_quant_bf16_rounds_operands_only():
     c = orc.OracleModel(**t2, quant=0).score_pairs([0, 1, 2], [0, 1, 2])
     np.testing.assert_array_equal(b, c)
     assert np.abs(a - b).max() < 1e-2
+
+
+def test_e4m3_rounding_matches_torch_cpu_cast():
+    """The oracle's (and, bit for bit, the device's) OCP e4m3fn rounding against torch's CPU float8_e4m3fn cast:
+    identical inside the finite range (normals, subnormals, ties, signed zero); beyond 464 torch yields NaN where the
+    quantiser saturates at 448 (the scale 448/max|x| never produces such inputs)."""
+    import torch
+    from oracle import oracle as orc
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.standard_normal(100000).astype(np.float32) * np.float32(30),
+                        rs.standard_normal(50000).astype(np.float32) * np.float32(0.01),
+                        np.float32(2.0) ** rs.randint(-12, 9, size=20000).astype(np.float32) * rs.choice([1.0, 1.0625, 1.125, 1.1875], 20000).astype(np.float32),
+                        np.array([0.0, -0.0, 2.0 ** -10, 2.0 ** -9, 3 * 2.0 ** -10, 448.0, 447.9, 463.9, -463.9], np.float32)])
+    x = x[np.abs(x) < 464.0]
+    want = torch.tensor(x).to(torch.float8_e4m3fn).float().numpy()
+    got = orc.e4m3_round(x)
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.signbit(got), np.signbit(want))
+    assert orc.e4m3_round(np.array([1e4, -1e4], np.float32)).tolist() == [448.0, -448.0]
