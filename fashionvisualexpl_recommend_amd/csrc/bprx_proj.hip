@@ -788,6 +788,124 @@ __global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// forward v9: as v8 (one balanced workgroup per CU), but the A operand (feature rows) is loaded like the backward
+// kernel loads its tiles -- every thread moves contiguous 16-B pieces of the tiled F (a 16-row tile x 128-column chunk
+// is one contiguous 4-KB run), registers -> LDS, and the MFMA fragments are read from LDS -- instead of 16-row x 64-B
+// fragment loads straight into VGPRs.  Plain C++ (the compiler keeps counted vmcnt for unconditional loads, see the
+// backward kernel); PD9 chunks in flight in registers, one LDS image, two barriers per chunk.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, bool F8>
+__global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
+                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger,
+                                                          const float *__restrict__ pscale, int tiles_per_wave, int n0) {
+  constexpr int RB = 288;                                  // LDS row stride, bytes (256 B of a chunk row + 32)
+  constexpr int APT = 8;                                   // A pieces per thread and chunk (16 tiles x 256 pieces / 512)
+  constexpr int NPIECE = NT * 16 * 16;                     // 16-B pieces of one [E|Bp]^T chunk
+  constexpr int NBP = (NPIECE + 5 * 64 - 1) / (5 * 64);
+  constexpr int PD9 = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds9[];
+  unsigned char *As = lds9;                                // [256 rows][RB]
+  unsigned char *Bs = lds9 + 256 * RB;                     // [NT*16 rows][RB]
+  const int tid = threadIdx.x, bdim = (int)blockDim.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int T = (nrows + 15) >> 4;
+  const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
+  const int ntile = t1 - t0, napiece = ntile * 256;        // 16 rows x 16 pieces per tile
+  const int first = w * tiles_per_wave;                    // this wave's tiles, workgroup-local numbering
+  const int nlive = (first < ntile ? 1 : 0) + ((tiles_per_wave == 2 && first + 1 < ntile) ? 1 : 0);
+  // per A piece of this thread: where its row starts in the tiled F (pieces past the end repeat the last one)
+  const uint16_t *abase[APT];
+  int alds[APT];
+#pragma unroll
+  for (int x = 0; x < APT; ++x) {
+    int pc = tid + x * bdim;
+    pc = pc < napiece ? pc : (napiece > 0 ? napiece - 1 : 0);
+    int t = t0 * 16 + (pc >> 4);
+    if (t >= nrows) t = nrows - 1;
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    abase[x] = F + ft_row(item, D) + (pc & 15) * 8;
+    alds[x] = (pc >> 4) * RB + (pc & 15) * 16;
+  }
+#define V9_BPIECE(x) ((tid + (x) * bdim) < NPIECE ? (tid + (x) * bdim) : NPIECE - 1)   /* no lambda: a by-reference capture
+                                                                                          puts the arrays in scratch */
+  const uint16_t *Et0 = Et + (size_t)n0 * 128;
+  const int nch = D / KC;
+  const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4_t areg0[APT], areg1[APT], breg0[NBP], breg1[NBP];   // first-class vectors: a uint4 struct copy becomes a memcpy
+                                                            // through a private array the compiler then keeps in scratch
+#define V9_ISSUE(ST, C)                                                                                              \
+  {                                                                                                                  \
+    int cc_ = (C);                                                                                                   \
+    cc_ = cc_ < nch ? cc_ : nch - 1;                                                                                 \
+    int ce_ = cc_ + cshift;                                                                                          \
+    if (ce_ >= nch) ce_ -= nch;                                                                                      \
+    const size_t kb_ = (size_t)ce_ << 12;                     /* chunk ce_ of a tiled row: ce_ * 4096 units */       \
+    _Pragma("unroll") for (int x = 0; x < APT; ++x) areg##ST[x] = *reinterpret_cast<const i32x4_t *>(abase[x] + kb_);  \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x)                                                                  \
+        breg##ST[x] = *reinterpret_cast<const i32x4_t *>(Et0 + (size_t)ce_ * (PS * 128) + V9_BPIECE(x) * 8);           \
+  }
+#define V9_COMMIT(ST)                                                                                                \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int x = 0; x < APT; ++x) *reinterpret_cast<i32x4_t *>(As + alds[x]) = areg##ST[x];         \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                \
+      const int pc = V9_BPIECE(x);                                                                                   \
+      *reinterpret_cast<i32x4_t *>(Bs + (pc >> 4) * RB + (pc & 15) * 16) = breg##ST[x];                                \
+    }                                                                                                                \
+  }
+#define V9_COMPUTE()                                                                                                 \
+  if (nlive > 0) {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < KC / 32; ++ks) {                                                         \
+      const i32x4_t a0 = *reinterpret_cast<const i32x4_t *>(As + (first * 16 + r) * RB + ks * 64 + q * 16);          \
+      const i32x4_t a1 = *reinterpret_cast<const i32x4_t *>(As + ((nlive == 2 ? first + 1 : first) * 16 + r) * RB + ks * 64 + q * 16); \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                            \
+        const i32x4_t b = *reinterpret_cast<const i32x4_t *>(Bs + (nt * 16 + r) * RB + ks * 64 + q * 16);            \
+        acc[0][nt] = mfma_frag<F8>(a0, b, acc[0][nt]);                                                               \
+        acc[1][nt] = mfma_frag<F8>(a1, b, acc[1][nt]);   /* a wave with one tile computes it twice, stores once */   \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+  V9_ISSUE(0, 0)
+  V9_ISSUE(1, 1)
+  for (int c0 = 0; c0 < nch; c0 += 2) {                       // nch is even; stages written out (areg/breg stay in registers)
+    __syncthreads();
+    V9_COMMIT(0)
+    __syncthreads();
+    V9_ISSUE(0, c0 + 2)
+    V9_COMPUTE()
+    __syncthreads();
+    V9_COMMIT(1)
+    __syncthreads();
+    V9_ISSUE(1, c0 + 3)
+    V9_COMPUTE()
+  }
+#undef V9_COMPUTE
+#undef V9_ISSUE
+#undef V9_COMMIT
+#undef V9_BPIECE
+  const float ps = F8 ? *pscale : 1.0f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (mt >= nlive) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = (t0 + first + mt) * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + n0 + nt * 16 + r] = acc[mt][nt][reg] * ps;
+      }
+    }
+  }
+}
+
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
                                                       float *__restrict__ dEp, float gscale) {
@@ -839,6 +957,30 @@ extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generat
 
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
 #define FWD_ARGS (const uint16_t *)h->Ft, rows, (int)nrows, h->cfg.num_items, Deq, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
+template <int NT>
+void launch_v9(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
+               const float *pscale, int stagger, int n0) {
+  const int64_t T = (nrows + 15) / 16;
+  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+  int64_t G = (T + 15) / 16;
+  if (G < ncu) G = T < ncu ? T : ncu;
+  else G = (G + ncu - 1) / ncu * ncu;
+  const int tpw_max = (int)((T + G - 1) / G);
+  const int per_wave = tpw_max > 8 ? 2 : 1;
+  int nw = (tpw_max + per_wave - 1) / per_wave;
+  if (nw < 5) nw = 5;
+  const size_t lds = (size_t)(256 + NT * 16) * 288;
+  if (f8) {
+    auto kfn = k_proj_fwd_bf16_v9<NT, true>;
+    (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, FWD_ARGS, stagger, pscale, per_wave, n0);
+  } else {
+    auto kfn = k_proj_fwd_bf16_v9<NT, false>;
+    (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, FWD_ARGS, stagger, pscale, per_wave, n0);
+  }
+}
+
 template <int NT>
 void launch_v8(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
                const float *pscale, int stagger, int n0) {
@@ -899,6 +1041,12 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
         case 15: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 15>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
         default: break;
       }
+    }
+  }
+  if constexpr (NT <= 9) {
+    if (v == 5 && Deq % 256 == 0) {                      // v9: A operand through LDS, contiguous loads of the tiled F
+      launch_v9<NT>(h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, 0);
+      return 0;
     }
   }
   if (v == 4 && Deq % 256 == 0) {
