@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
                                                       const int32_t *__restrict__ neg, int64_t B) {
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
+  // `full`: every lane group of this workgroup has a triplet (all but the last workgroup): only then may the workgroup
+  // meet at barriers (user-row combination below); in a partial workgroup the surplus groups leave here
+  const bool full = ((int64_t)(blockIdx.x + 1) * 256) / G <= B;
   if (b >= B) return;
   const int u = clamp_idx(user[b], a.U, a.errflag, 1);
   const int i = clamp_idx(pos[b], a.I, a.errflag, 2), j = clamp_idx(neg[b], a.I, a.errflag, 3);
@@ -262,11 +265,30 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
     comb = !exU && (__ballot(1) == ~0ull) && __all(u == u0);
   }
   const bool lead = (threadIdx.x & 63) < G;
+  // ... and when all four waves of the workgroup work on that same user (runs of ~20 triplets per user in the epoch
+  // order), the four wave sums meet in LDS and are added once: 256/G times fewer atomic bytes than one add per triplet
+  // (at k = d = 256 a lane group IS a wave: 4x; without this the kernel is atomic-bound there).
+  constexpr int WGROW = 1024;                             // floats per wave row in LDS (k + d <= WGROW)
+  __shared__ int s_u[4];
+  __shared__ float s_du[4][WGROW];
+  bool wgc = false;
+  const int wv = threadIdx.x >> 6;
+  if (full && k + d <= WGROW) {
+    const int u0 = __shfl(u, 0, 64);
+    const bool wave_ok = G == 64 ? !exU : comb;
+    if ((threadIdx.x & 63) == 0) s_u[wv] = wave_ok ? u0 : -1 - wv;
+    __syncthreads();
+    wgc = s_u[0] >= 0 && s_u[0] == s_u[1] && s_u[1] == s_u[2] && s_u[2] == s_u[3];
+  }
   for (int c = lane; c < k; c += G) {
     const float p = gu[c], q = gi[c], r = gj[c];
     float du = g * (q - r) + r2 * p;
     if (exU) pu[c] = p - lr * du;
-    else if (comb) {
+    else if (wgc) {
+#pragma unroll
+      for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
+      if (lead) s_du[wv][c] = du;
+    } else if (comb) {
 #pragma unroll
       for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
       if (lead) atomicAdd(au + c, du);
@@ -289,7 +311,11 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       if (!last) {
         float dt = g * (Pi[c] - Pj[c]) + r2 * p;
         if (exU) pt[c] = p - lr * dt;
-        else if (comb) {
+        else if (wgc) {
+#pragma unroll
+          for (int o = G; o < 64; o <<= 1) dt += __shfl_xor(dt, o, 64);
+          if (lead) s_du[wv][k + c] = dt;
+        } else if (comb) {
 #pragma unroll
           for (int o = G; o < 64; o <<= 1) dt += __shfl_xor(dt, o, 64);
           if (lead) atomicAdd(at + c, dt);
@@ -298,6 +324,14 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       // W is all-zero before the step: a sole contributor stores
       if (iaI) { if (exI) wi[c] = g * p; else atomicAdd(wi + c, g * p); }
       if (iaJ) { if (exJ) wj[c] = -g * p; else atomicAdd(wj + c, -g * p); }
+    }
+  }
+  if (wgc) {                                              // workgroup-uniform
+    __syncthreads();
+    const int uw = s_u[0];
+    for (int e = threadIdx.x; e < k + d; e += 256) {
+      const float sum = (s_du[0][e] + s_du[1][e]) + (s_du[2][e] + s_du[3][e]);
+      atomicAdd(e < k ? a.dGu + (size_t)uw * k + e : a.dTu + (size_t)uw * d + (e - k), sum);
     }
   }
 }
