@@ -2,6 +2,8 @@
 GPU engine vs CPU oracle on the IDENTICAL reference index stream -> HR@10 / NDCG@10 within 1e-3 (north_star)."""
 from argparse import Namespace
 
+import os
+
 import numpy as np
 import pytest
 
@@ -108,3 +110,33 @@ def test_vbpr_from_feature_file_metric_parity(tmp_path, dtype, quant):
     tol = 1e-3 if dtype == "fp32" else 2e-2
     for key in ("hr_v", "ndcg_v", "hr_t", "ndcg_t"):
         assert abs(results[3][key] - want[key]) <= tol, (key, results[3][key], want[key])
+
+
+def test_train_rec_cli_surface_writes_the_reference_outputs(tmp_path):
+    """`train_rec.py`'s flag surface end to end (train_rec.py:17-93): two regularisation values, VBPR from a feature
+    file, and the output files of BPRMF.py:156-183 / utils/write.py (weights snapshots, recs-*.tsv, best-recs,
+    results-metrics pickle) under the reference's directory naming."""
+    import glob
+    import pickle
+    from fashionvisualexpl_recommend_amd import train_rec
+    U, I, D = 120, 150, 128
+    tr, va, te = synth.make_interactions_clustered(U, I, per_user=12, clusters=6, p_in=0.9, seed=5)
+    feats = np.abs(np.random.RandomState(1).standard_normal((I, D))).astype(np.float32)
+    synth.write_dataset(str(tmp_path), "cli", tr, va, te, I, features=feats)
+    res = train_rec.train(["--dataset", "cli", "--rec", "vbpr", "--batch_size", "64", "--epochs", "2", "--embed_k", "8",
+                           "--embed_d", "4", "--lr", "0.05", "--list_of_regs", "0.0", "0.001", "--top_k", "5", "--verbose", "1",
+                           "--optimizer", "sgd", "--dtype", "bf16", "--data_root", str(tmp_path),
+                           "--results_root", str(tmp_path / "results"), "--gpu", "0"])
+    assert len(res) == 2 and all(sorted(r) == [1, 2] for r in res)
+    for reg in ("0.0", "0.001"):
+        tag = "batch_64-D_4-K_8-lr_0.05-reg_%s" % reg
+        rdir = os.path.join(configs.results_dir(), "cli", "vbpr")
+        wdir = os.path.join(configs.weight_dir(), "cli", "vbpr")
+        assert os.path.exists(os.path.join(rdir, "recs-2-%s.tsv" % tag))
+        assert glob.glob(os.path.join(rdir, "best-recs-*-%s.tsv" % tag))
+        assert glob.glob(os.path.join(wdir, "weights-1-%s.pt" % tag)) and glob.glob(os.path.join(wdir, "best-weights-*-%s.pt" % tag))
+        with open(os.path.join(rdir, "results-metrics-%s.pkl" % tag), "rb") as f:      # written by this run (our own file)
+            m = pickle.load(f)
+        assert set(m[2]) == {"hr_v", "auc_v", "p_v", "r_v", "ndcg_v", "hr_t", "auc_t", "p_t", "r_t", "ndcg_t"}
+        rows = open(os.path.join(rdir, "recs-2-%s.tsv" % tag)).read().strip().split("\n")
+        assert len(rows) == U * 5 and len(rows[0].split("\t")) == 3
