@@ -94,8 +94,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
     if (h->SK < 1) h->SK = 1;
     if (h->SK > 256) h->SK = 256;
-    // defaults = the fastest measured variants (profiles/r01_sweeps.md): forward v6 (asm-pinned ping-pong pipeline,
-    // staggered chunk order; falls back to v1 when D % 256 != 0), backward v3 (bf16 W, conflict-free LDS image).
+    // defaults = the fastest measured variants (profiles/r01_sweeps.md); env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT override
     h->fwd_variant = 12;   // v8: one balanced 5..8-wave workgroup per CU, staggered chunk order (falls back to v6 / v1)
     h->bwd_variant = 26;   // v3, 8 waves (256 columns) per workgroup, 2 tiles in flight, XCD-aware split placement
     if (const char *e = getenv("BPRX_FWD_VARIANT")) h->fwd_variant = atoi(e);

@@ -1016,9 +1016,10 @@ void launch_v8_rt(int nt, bprx_handle *h, const int32_t *rows, int64_t nrows, fl
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   constexpr int MTD = NT <= 9 ? 2 : 1;
-  // fwd_variant: 0 = v1 (2 barriers per chunk, nothing overlapped), 1 = v1 with one row tile per wave,
-  //              2 = v6 (asm-pinned ping-pong pipeline), 3 = v6 with one row tile per wave; +8 = staggered chunk order;
-  //              +16 / +32 = v1 timing-only ablations (skip the B / A loads)
+  // fwd_variant & 7: 0 = v1 (2 barriers per chunk, nothing overlapped), 1 = v1 with one row tile per wave,
+  //              2 = v6 (asm-pinned ping-pong pipeline, 4-wave workgroups of 128 items), 3 = v6 with one row tile per wave,
+  //              4 = v8 (default: one balanced workgroup per CU), 5 = v9 (A operand through LDS; experiment);
+  //              +8 = staggered chunk order; +16 / +32 / +64 = timing-only ablations of v1 / v6 (wrong results)
   const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3);
   const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
   const int Deq = f8 ? h->cfg.feat_dim / 2 : h->cfg.feat_dim;
