@@ -102,6 +102,11 @@ BPRX_API int bprx_create(const bprx_config *cfg, bprx_handle **out);
 BPRX_API int bprx_destroy(bprx_handle *h);
 BPRX_API const char *bprx_last_error(const bprx_handle *h); /* h == NULL: error of the last failed bprx_create */
 
+/* Binds caller-owned device tables (they stay owned by the caller and are updated in place by the steps).
+   bf16 / fp8 features: F is frozen (visual_loader_mixin.py:22-31) -- this call copies it ONCE into a tiled layout the
+   projections read (synchronous; work is enqueued on the null stream, so F must be complete with respect to it); the
+   caller's F is not read again until the next bprx_bind_tables and may be released.
+   A handle is not thread-safe; all other entry points only enqueue work on the stream they are given. */
 BPRX_API int bprx_bind_tables(bprx_handle *h, const bprx_tables *t);
 BPRX_API int bprx_set_hyper(bprx_handle *h, float lr, float reg);           /* train_rec.py:69 (args.reg = reg) */
 BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations);         /* optimizer.iterations (resume) */
