@@ -99,6 +99,7 @@ class Engine:
         tb = _ffi.Tables()
         for n in _ffi.TABLE_FIELDS:
             setattr(tb, n, None if t.get(n) is None else t[n].data_ptr())
+        torch.cuda.current_stream(self.device).synchronize()   # bind tiles F on the null stream: the tables must be complete
         _ffi.check(self.h, self.lib.bprx_bind_tables(self.h, C.byref(tb)))
         self.t = t
         return self
