@@ -53,6 +53,8 @@ def parse():
                          "epoch-walk sampler (the reference's visiting order: user-grouped batches); pregen: resident "
                          "pre-generated index batches")
     ap.add_argument("--pos-per-user", type=int, default=20)
+    ap.add_argument("--zipf", type=float, default=0.0,
+                    help="> 0: positives follow a Zipf(s) item popularity instead of the uniform one (hot items)")
     ap.add_argument("--dist-mode", default="replicated", choices=["replicated", "a2a"],
                     help="N > 1, VBPR: replicated = user tables on every rank, one all-gather per step (default); "
                          "a2a = user tables range-partitioned, rows fetched / gradients returned by all-to-all")
@@ -201,7 +203,15 @@ def main():
         from fashionvisualexpl_recommend_amd.engine import EpochWalkSampler, PhiloxSampler
         npu = args.pos_per_user
         # (N > 1: every GLOBAL user has pos-per-user positives inside this rank's item shard)
-        items = torch.randint(samp_items, (samp_users, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
+        if args.zipf > 0:
+            # Zipf(s) item popularity (SURVEY 8(d) "throughput realism" variant): item ranks drawn by inverse-CDF from
+            # weights 1/rank^s; duplicates inside a user's list are allowed (they only make that positive likelier)
+            wts = 1.0 / torch.arange(1, samp_items + 1, device=device, dtype=torch.float64) ** args.zipf
+            cdf = torch.cumsum(wts / wts.sum(), 0)
+            r = torch.rand((samp_users, npu), generator=gi, device=device, dtype=torch.float64)
+            items = torch.searchsorted(cdf, r).clamp_(max=samp_items - 1).to(torch.int32).sort(dim=1).values
+        else:
+            items = torch.randint(samp_items, (samp_users, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
         indptr = torch.arange(samp_users + 1, device=device, dtype=torch.int64) * npu
         pos_user = torch.arange(samp_users, device=device, dtype=torch.int32).repeat_interleave(npu)
         cls = EpochWalkSampler if args.sampler == "epoch" else PhiloxSampler
@@ -330,7 +340,8 @@ def main():
                        "sampler": (("device philox, uniform positive + rejection negative" if args.sampler == "philox" else
                                     "device epoch walk (every positive once per epoch, user-grouped) + philox negative")
                                    + ", one batch per step inside the timed region%s (%d positives/user)"
-                                   % (", drawn one step ahead on a side stream" if pipe else "", args.pos_per_user))
+                                   % (", drawn one step ahead on a side stream" if pipe else "", args.pos_per_user)
+                                   + (", Zipf(%.2f) item popularity" % args.zipf if args.zipf > 0 else ""))
                        if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,
             "step_roofline": {"bytes_per_triplet": per_trip, "achieved": value * per_trip / 1e9 / world,

@@ -47,6 +47,7 @@ struct bprx_handle {
   int32_t *seg_rank;              // [2 * max_batch] rank of occurrence (role*B + b) among its item's occurrences
   int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent (valid for items of the current batch)
   int32_t *seg_cursor;            // [1] bump allocator of segments
+  int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
   int num_cu;                     // compute units of the device (balanced forward grid)
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)

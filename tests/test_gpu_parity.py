@@ -257,19 +257,22 @@ def test_sgd_mostly_exclusive_rows_with_some_duplicates(model, item_mode, monkey
 
 @pytest.mark.parametrize("model,opt,item_mode", [("bprmf", "sgd", 2), ("bprmf", "adam_tf23", 2), ("vbpr", "sgd", 2),
                                                  ("vbpr", "adam_tf23", 2), ("vbpr", "sgd", 0), ("bprmf", "sgd", 0),
-                                                 ("vbpr", "sgd", 1)])
+                                                 ("vbpr", "sgd", 1), ("vbpr_fp32", "sgd", 2), ("vbpr_fp32", "adam_tf23", 2)])
 def test_hot_items_segments_and_atomic_excess(model, opt, item_mode, monkeypatch):
     """Item-side gradients by occurrence segments (BPRX_ITEM_MODE 2 = always; 1 = per step when 2B >= I, the default)
-    and by global atomics (0) give the same batch-synchronous step.  One item occurs 180 times (as positive AND as negative): more than the 64 entries a
-    segment is walked for, so its excess goes through the atomic staging tables and is folded in by k_item_seg."""
+    and by global atomics (0) give the same batch-synchronous step (bf16 and fp32 feature tables).  One item occurs 180
+    times (as positive AND as negative), another 70 times: more than the 32 entries one lane group walks, so they are
+    cut into chunks whose partial sums meet in the staging rows and are completed by the last chunk to finish."""
     monkeypatch.setenv("BPRX_ITEM_MODE", str(item_mode))
     U, I, k, B = 400, 300, 32, 512
+    fdt = "fp32" if model == "vbpr_fp32" else "bf16"
+    model = "vbpr" if model.startswith("vbpr") else model
     d, D = (20, 128) if model == "vbpr" else (0, 0)
-    t = _tables(U, I, k, d, D, seed=13, bf16=(model == "vbpr"))
-    kw = dict(embed_d=d, feat_dim=D, feat_dtype="bf16") if model == "vbpr" else {}
+    t = _tables(U, I, k, d, D, seed=13, bf16=(model == "vbpr" and fdt == "bf16"))
+    kw = dict(embed_d=d, feat_dim=D, feat_dtype=fdt) if model == "vbpr" else {}
     lr = 0.05 if opt == "sgd" else 0.01
     e = _engine(model=model, num_users=U, num_items=I, embed_k=k, optimizer=opt, lr=lr, reg=1e-3, max_batch=B, **kw).bind(**t)
-    o = orc.OracleModel(**t, quant=1 if model == "vbpr" else 0)
+    o = orc.OracleModel(**t, quant=1 if (model == "vbpr" and fdt == "bf16") else 0)
     for step in range(3):
         u, i, j = _batch(U, I, B, 60 + step)
         i[:100] = 3
