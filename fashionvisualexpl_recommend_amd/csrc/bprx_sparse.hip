@@ -553,11 +553,12 @@ __device__ __forceinline__ uint16_t f2bf_s(float x) {   // round-to-nearest-even
 //                     acc_g += +-g*gamma_u     acc_t += +-g*theta_u     gsum += +-g
 //                  then finishes the item in one pass: the L2-regularised gradient is applied to Gi/Bi in place (sgd) or
 //                  stored to the staging tables (adam), and the W row of the backward projection is written once
-//                  (bf16 for the MFMA path: no conversion pass; untouched rows come from one memset of the bf16 image).
+//                  (bf16 for the MFMA path: no conversion pass; k_row_count re-zeroed the image, so untouched rows are zero).
 // The user side reads pre-update item rows in k_triplet_grad, which has completed before k_item_seg starts.
 // Global float atomics moved 1032 of the 1544 B per triplet at ~1 TB/s (the chip-wide atomic rate); here the same bytes
-// are plain 16-B-per-lane row gathers.  Items hotter than SEG_CAP occurrences keep the excess on the atomic path
-// (bounded serial walk per group); k_item_seg folds the staged excess in and re-zeroes it.
+// are plain 16-B-per-lane row gathers.  A segment longer than SEG_CAP entries (hot item) is cut into chunks of SEG_CAP,
+// one lane group each (led by the occurrences of rank 0, SEG_CAP, 2 SEG_CAP, ...): bounded serial walk per group; the
+// chunks' partial sums meet in the item's staging rows and the chunk that finishes last completes the item.
 // ------------------------------------------------------------------------------------------------------------
 template <int G, bool ADAM>
 __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
