@@ -581,36 +581,37 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   float gsum = 0.f;
   int nj = 0;
   int e = 0;
+  // Row loads are unconditional (lanes past the row end re-read column 0 and are masked in the sums): with the loads
+  // inside per-lane `if (hk)` / `if (hd)` regions the compiler waits for the gamma rows before it issues the theta
+  // rows -- three dependent round trips per iteration instead of two.
+  const int ck = hk ? c4 : 0, cd = hd ? c4 : 0;
+  const float mk = hk ? 1.f : 0.f, md = hd ? 1.f : 0.f;
+  const float *TuS = d ? a.Tu : a.Gu;                                 // d == 0: any valid address, md == 0
+  const int ds = d ? d : k;
   for (; e + 2 <= ns; e += 2) {                                       // two entries in flight
     const int2 r0 = ent[e], r1 = ent[e + 1];
     const int u0 = r0.x & 0x7fffffff, u1 = r1.x & 0x7fffffff;
+    const float4 p0 = ld4(a.Gu + (size_t)u0 * k + ck), p1 = ld4(a.Gu + (size_t)u1 * k + ck);
+    const float4 t0 = ld4(TuS + (size_t)u0 * ds + cd), t1 = ld4(TuS + (size_t)u1 * ds + cd);
     const float s0 = r0.x < 0 ? -__int_as_float(r0.y) : __int_as_float(r0.y);
     const float s1 = r1.x < 0 ? -__int_as_float(r1.y) : __int_as_float(r1.y);
     nj += (r0.x < 0) + (r1.x < 0);
     gsum += s0 + s1;
-    if (hk) {
-      const float4 p0 = ld4(a.Gu + (size_t)u0 * k + c4), p1 = ld4(a.Gu + (size_t)u1 * k + c4);
-      ag.x += s0 * p0.x + s1 * p1.x; ag.y += s0 * p0.y + s1 * p1.y; ag.z += s0 * p0.z + s1 * p1.z; ag.w += s0 * p0.w + s1 * p1.w;
-    }
-    if (hd) {
-      const float4 p0 = ld4(a.Tu + (size_t)u0 * d + c4), p1 = ld4(a.Tu + (size_t)u1 * d + c4);
-      at.x += s0 * p0.x + s1 * p1.x; at.y += s0 * p0.y + s1 * p1.y; at.z += s0 * p0.z + s1 * p1.z; at.w += s0 * p0.w + s1 * p1.w;
-    }
+    const float g0 = s0 * mk, g1 = s1 * mk, h0 = s0 * md, h1 = s1 * md;
+    ag.x += g0 * p0.x + g1 * p1.x; ag.y += g0 * p0.y + g1 * p1.y; ag.z += g0 * p0.z + g1 * p1.z; ag.w += g0 * p0.w + g1 * p1.w;
+    at.x += h0 * t0.x + h1 * t1.x; at.y += h0 * t0.y + h1 * t1.y; at.z += h0 * t0.z + h1 * t1.z; at.w += h0 * t0.w + h1 * t1.w;
   }
   if (e < ns) {
     const int2 r0 = ent[e];
     const int u0 = r0.x & 0x7fffffff;
+    const float4 p0 = ld4(a.Gu + (size_t)u0 * k + ck);
+    const float4 t0 = ld4(TuS + (size_t)u0 * ds + cd);
     const float s0 = r0.x < 0 ? -__int_as_float(r0.y) : __int_as_float(r0.y);
     nj += (r0.x < 0);
     gsum += s0;
-    if (hk) {
-      const float4 p0 = ld4(a.Gu + (size_t)u0 * k + c4);
-      ag.x += s0 * p0.x; ag.y += s0 * p0.y; ag.z += s0 * p0.z; ag.w += s0 * p0.w;
-    }
-    if (hd) {
-      const float4 p0 = ld4(a.Tu + (size_t)u0 * d + c4);
-      at.x += s0 * p0.x; at.y += s0 * p0.y; at.z += s0 * p0.z; at.w += s0 * p0.w;
-    }
+    const float g0 = s0 * mk, h0 = s0 * md;
+    ag.x += g0 * p0.x; ag.y += g0 * p0.y; ag.z += g0 * p0.z; ag.w += g0 * p0.w;
+    at.x += h0 * t0.x; at.y += h0 * t0.y; at.z += h0 * t0.z; at.w += h0 * t0.w;
   }
   const float r2 = 2.f * a.reg;
   const float fn = (float)ns, fj = (float)nj, fi = (float)(ns - nj);
