@@ -198,10 +198,11 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(const int32_t *__restrict__ 
 
 // One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
 // (or, for rows no other triplet of the batch uses, the finished sgd update straight into the table).
-template <int G, bool VEC>
-__global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
-                                                      const int32_t *__restrict__ pos,
-                                                      const int32_t *__restrict__ neg, int64_t B) {
+// SEG: the launch is in segment mode (a.item_atomics == 0); a compile-time flag so that the register-sourced backward of
+// the user side (below) costs the atomic-mode instantiation nothing.
+template <int G, bool VEC, bool SEG>
+__device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int32_t *__restrict__ user,
+                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   // `full`: every lane group of this workgroup has a triplet (all but the last workgroup): only then may the workgroup
@@ -217,9 +218,12 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
 
   // ---- forward: the un-differenced per-item scores of the reference (BPRMF.py:101-102) ----
   float si = 0.f, sj = 0.f, nrm = 0.f;   // <gu,gi>, <gu,gj>, |gu|^2+|gi|^2+|gj|^2 (+|tu|^2)
+  // rows of the (usually only) forward pass, kept for the LDS-combined backward of the user side
+  float4 fp = make_float4(0.f, 0.f, 0.f, 0.f), fq = fp, fr = fp, tp = fp, tq = fp, tr = fp;
   if (VEC) {
     for (int c = lane * 4; c < k; c += G * 4) {
       float4 p = ld4(gu + c), q = ld4(gi + c), r = ld4(gj + c);
+      if (SEG && G >= 32) { fp = p; fq = q; fr = r; }
       si += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
       sj += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
       nrm += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w + q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w +
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
     if (VEC) {
       for (int c = lane * 4; c < d; c += G * 4) {
         float4 p = ld4(tu + c), q = ld4(Pi + c), r = ld4(Pj + c);
+        if (SEG && G >= 32) { tp = p; tq = q; tr = r; }
         ti += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
         tj += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
         nrm += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   // (at k = d = 256 a lane group IS a wave: 4x; without this the kernel is atomic-bound there).
   constexpr int WGROW = 1024;                             // floats per wave row in LDS (k + d <= WGROW)
   __shared__ int s_u[4];
-  __shared__ float s_du[4][WGROW];
+  __shared__ __attribute__((aligned(16))) float s_du[4][WGROW];
   bool wgc = false;
   const int wv = threadIdx.x >> 6;
   if (full && k + d <= WGROW) {
@@ -314,7 +319,27 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
     __syncthreads();
     wgc = s_u[0] >= 0 && s_u[0] == s_u[1] && s_u[1] == s_u[2] && s_u[2] == s_u[3];
   }
-  for (int c = lane; c < k; c += G) {
+  // Segment mode with a workgroup-wide user (the common case in epoch order): nothing of the item side is left to do
+  // here and the user-row gradient goes to LDS, so the backward pass needs NO second read of the rows in the
+  // lane = element layout -- it is formed from the forward pass's registers (16 B per lane) and summed across the groups.
+  // (wide rows only, G >= 32: at G = 16 the 27 four-byte re-reads are L1 hits and cheaper than the extra live registers:
+  //  measured 38 -> 40 us on C2, 62 -> 55 us at k = d = 128, 106 -> 84 us at k = d = 256)
+  const bool from_regs = SEG && G >= 32 && VEC && wgc && !iaI && k <= 4 * G && d <= 4 * G;
+  if (from_regs) {
+    const int c = lane * 4;
+    float4 du = make_float4(g * (fq.x - fr.x) + r2 * fp.x, g * (fq.y - fr.y) + r2 * fp.y, g * (fq.z - fr.z) + r2 * fp.z,
+                            g * (fq.w - fr.w) + r2 * fp.w);
+    float4 dt = make_float4(g * (tq.x - tr.x) + r2 * tp.x, g * (tq.y - tr.y) + r2 * tp.y, g * (tq.z - tr.z) + r2 * tp.z,
+                            g * (tq.w - tr.w) + r2 * tp.w);
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+      du.x += __shfl_xor(du.x, o, 64); du.y += __shfl_xor(du.y, o, 64); du.z += __shfl_xor(du.z, o, 64); du.w += __shfl_xor(du.w, o, 64);
+      dt.x += __shfl_xor(dt.x, o, 64); dt.y += __shfl_xor(dt.y, o, 64); dt.z += __shfl_xor(dt.z, o, 64); dt.w += __shfl_xor(dt.w, o, 64);
+    }
+    if (lead && c < k) *reinterpret_cast<float4 *>(&s_du[wv][c]) = du;
+    if (lead && c < d) *reinterpret_cast<float4 *>(&s_du[wv][k + c]) = dt;
+  }
+  for (int c = lane; c < (from_regs ? 0 : k); c += G) {
     const float p = gu[c], q = gi[c], r = gj[c];
     float du = g * (q - r) + r2 * p;
     if (exU) pu[c] = p - lr * du;
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj);
     }
   }
-  if (d) {
+  if (d && !from_regs) {
     float *at = a.dTu + (size_t)u * d, *pt = a.wTu + (size_t)u * d;
     float *wi = a.W + (size_t)i * a.PS, *wj = a.W + (size_t)j * a.PS;
     for (int c = lane; c <= d; c += G) {                 // c == d: the Bp column of [theta_u | 1]
@@ -368,6 +393,17 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
       atomicAdd(e < k ? a.dGu + (size_t)uw * k + e : a.dTu + (size_t)uw * d + (e - k), sum);
     }
   }
+}
+
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
+                                                      const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
+  triplet_grad_body<G, VEC, false>(a, user, pos, neg, B);
+}
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_triplet_grad_seg(SparseArgs a, const int32_t *__restrict__ user,
+                                                          const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
+  triplet_grad_body<G, VEC, true>(a, user, pos, neg, B);
 }
 
 // sgd: one group per occurrence; the first to claim a touched row applies  p -= lr*dG  and re-zeroes dG.
@@ -914,7 +950,8 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   const bool bf = h->cfg.feat_dtype != BPRX_F_FP32;     // bf16 W image (bf16 and fp8 features)
   if (a.d && (!bf || (!h->item_mode && h->bwd_variant < 8)))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
-  DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
+  if (h->item_mode) DISPATCH_G(G, vec, k_triplet_grad_seg, grid_for(B, G), s, a, u, i, j, B);
+  else DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
   return BPRX_OK;
 }
