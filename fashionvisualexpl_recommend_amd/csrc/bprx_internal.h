@@ -38,7 +38,9 @@ struct bprx_handle {
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
-  float *qs;                      // fp8 features: [0] = max|E,Bp| bits (uint32, atomicMax), [1] = 1/(feat_scale*sE) for P
+  float *qs;                      // fp8 features: [1] = 1/(feat_scale*sE) for P, [2], [3] = max|E,Bp| bits (uint32, atomicMax;
+                                  //               two slots used alternately, the idle one is cleared by k_cast_Et8)
+  int qs_slot;
   int fast_rows;                  // sgd: rows used by exactly one triplet of the batch are updated in place
   int32_t *cntU, *cntI;           // [U], [I] row multiplicities of the current batch (all-zero between steps)
   int seg_policy;                 // 0 never, 1 per step (2B >= I), 2 always (env BPRX_ITEM_MODE)

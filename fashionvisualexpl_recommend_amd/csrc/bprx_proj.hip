@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ E, siz
 // publishes qs[1] = 1 / (feat_scale * sE), the factor that turns the fp8 products back into P.
 __global__ __launch_bounds__(256) void k_cast_Et8(const float *__restrict__ E, const float *__restrict__ Bp,
                                                   uint8_t *__restrict__ Et, int D, int d, int PS, float *__restrict__ qs,
-                                                  float feat_scale) {
+                                                  float feat_scale, int slot) {
   __shared__ float tile[64][17];
-  const float amax = qs[0];
-  const float sE = amax > 0.f ? 448.0f / amax : 1.0f;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) qs[1] = 1.0f / (feat_scale * sE);
+  const float amax = qs[2 + slot];                         // written by k_absmax just before; the other slot is cleared here
+  const float sE = amax > 0.f ? 448.0f / amax : 1.0f;      // for the next step's k_absmax (no memset launch per step)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { qs[1] = 1.0f / (feat_scale * sE); qs[2 + (slot ^ 1)] = 0.f; }
   const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
   for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
     const int kr = idx >> 4, nc = idx & 15, kk = k0 + kr, n = n0 + nc;
@@ -1166,11 +1166,12 @@ int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
   BprxProfScope ps(h, BPRX_PHASE_CAST_ET, s);
   dim3 grid((D + 63) / 64, h->PS / 16);
   if (h->cfg.feat_dtype == BPRX_F_FP8) {
-    BPRX_HIP(h, hipMemsetAsync(h->qs, 0, sizeof(float), s));
+    const int slot = h->qs_slot;                            // max|E,Bp| accumulates in qs[2 + slot] (zero: cleared a step ago)
+    h->qs_slot ^= 1;
     hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, h->t.E, (size_t)D * h->cfg.embed_d, h->t.Bp, (size_t)D,
-                       (uint32_t *)h->qs);
+                       (uint32_t *)h->qs + 2 + slot);
     hipLaunchKernelGGL(k_cast_Et8, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint8_t *)h->Et, D, h->cfg.embed_d, h->PS, h->qs,
-                       h->cfg.feat_scale);
+                       h->cfg.feat_scale, slot);
     BPRX_LAUNCH_CHECK(h, "k_cast_Et8");
     return BPRX_OK;
   }
