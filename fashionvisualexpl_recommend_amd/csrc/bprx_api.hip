@@ -87,16 +87,26 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   if (vb) {
     h->PS = 16 * (int)((d + 1 + 15) / 16);
     const size_t PS = h->PS;
-    // split-K of the backward projection: about 1024 workgroups over D/128 column ranges
-    int mr = (int)((D + 127) / 128);
-    h->SK = (1024 + mr - 1) / mr;
+    // split-K of the backward projection: ONE 8-wave workgroup per CU over the D/256 column ranges (C2: 16 ranges x 16
+    // item splits on 256 CUs).  More splits only add slab traffic (SK*D*PS*4 B written, then read by the dense update):
+    // measured on C2 SK 16 / 32 with 3 / 2 tiles in flight: backward 73.8 / 77.0 us, dense update 9.7 / 12.1 us.
+    {
+      hipDeviceProp_t prop;
+      const int ncu = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256;
+      const int mr = (int)((D + 255) / 256);
+      h->SK = (ncu + mr - 1) / mr;
+      // fp8 tiles are half the bytes, wide projections (more than 9 column tiles) have no registers for a third tile in
+      // flight: both keep two workgroups per CU with two tiles in flight (measured: c2fp8 53 vs 58 us, c5 124 vs 362 us)
+      if (cfg->feat_dtype == BPRX_F_FP8 || PS / 16 > 9) h->SK *= 2;
+    }
     if (h->SK > 64) h->SK = 64;
     if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
     if (h->SK < 1) h->SK = 1;
     if (h->SK > 256) h->SK = 256;
     // defaults = the fastest measured variants (profiles/r01_sweeps.md); env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT override
     h->fwd_variant = 12;   // v8: one balanced 5..8-wave workgroup per CU, staggered chunk order (falls back to v6 / v1)
-    h->bwd_variant = 26;   // v3, 8 waves (256 columns) per workgroup, 2 tiles in flight, XCD-aware split placement
+    // v3, 8 waves (256 columns) per workgroup, XCD-aware split placement, 3 tiles in flight (2: fp8 / wide projections)
+    h->bwd_variant = (cfg->feat_dtype == BPRX_F_FP8 || PS / 16 > 9) ? 26 : 42;
     if (const char *e = getenv("BPRX_FWD_VARIANT")) h->fwd_variant = atoi(e);
     if (const char *e = getenv("BPRX_BWD_VARIANT")) h->bwd_variant = atoi(e);
     A(dalloc_zero(&h->dTu, U * d));
