@@ -840,7 +840,7 @@ __global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__r
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x4_t areg0[APT], areg1[APT], breg0[NBP], breg1[NBP];   // first-class vectors: a uint4 struct copy becomes a memcpy
+  i32x4_t areg0[APT], areg1[APT], areg2[APT], breg0[NBP], breg1[NBP], breg2[NBP];   // first-class vectors: a uint4 struct copy becomes a memcpy
                                                             // through a private array the compiler then keeps in scratch
 #define V9_ISSUE(ST, C)                                                                                              \
   {                                                                                                                  \
@@ -873,19 +873,31 @@ __global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__r
       }                                                                                                              \
     }                                                                                                                \
   }
+  // three chunks in flight (stages written out so that the staging registers keep static names); chunks past the end are
+  // clamped re-reads of the last chunk and are never committed
   V9_ISSUE(0, 0)
   V9_ISSUE(1, 1)
-  for (int c0 = 0; c0 < nch; c0 += 2) {                       // nch is even; stages written out (areg/breg stay in registers)
+  V9_ISSUE(2, 2)
+  for (int c0 = 0; c0 < nch; c0 += 3) {
     __syncthreads();
     V9_COMMIT(0)
     __syncthreads();
-    V9_ISSUE(0, c0 + 2)
+    V9_ISSUE(0, c0 + 3)
     V9_COMPUTE()
-    __syncthreads();
-    V9_COMMIT(1)
-    __syncthreads();
-    V9_ISSUE(1, c0 + 3)
-    V9_COMPUTE()
+    if (c0 + 1 < nch) {                                       // workgroup-uniform
+      __syncthreads();
+      V9_COMMIT(1)
+      __syncthreads();
+      V9_ISSUE(1, c0 + 4)
+      V9_COMPUTE()
+    }
+    if (c0 + 2 < nch) {
+      __syncthreads();
+      V9_COMMIT(2)
+      __syncthreads();
+      V9_ISSUE(2, c0 + 5)
+      V9_COMPUTE()
+    }
   }
 #undef V9_COMPUTE
 #undef V9_ISSUE
