@@ -16,3 +16,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """The C-ABI library and the oracle are built in-tree by __graft_entry__.build(); if a test run starts on a fresh
+    checkout, build them here (hipcc cross-compiles gfx950 without a GPU; ~75 s) instead of failing on a missing .so."""
+    from fashionvisualexpl_recommend_amd import _ffi
+    if not os.path.exists(_ffi.LIB_PATH):
+        from fashionvisualexpl_recommend_amd import build
+        build.build()
+    from oracle import oracle as orc
+    orc.build()
