@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbprx.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2
 
@@ -17,7 +17,7 @@ MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
 FEAT_DTYPE = {"fp32": 0, "bf16": 1, "fp8": 2}
 E_RANGE = -4
-PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count"]
+PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count", "cast_W_rows"]
 
 
 class BprxError(RuntimeError):
@@ -66,6 +66,8 @@ def lib():
         "bprx_last_error": (C.c_char_p, [vp]),
         "bprx_bind_tables": (C.c_int, [vp, C.POINTER(Tables)]),
         "bprx_set_hyper": (C.c_int, [vp, f32, f32]),
+        "bprx_tables_dirty": (C.c_int, [vp]),
+        "bprx_kernel_variant_safe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "bprx_set_adam_step": (C.c_int, [vp, i64]),
         "bprx_get_adam_step": (i64, [vp]),
         "bprx_score_pairs": (C.c_int, [vp, vp, vp, i64, vp, vp]),
@@ -103,7 +105,7 @@ def lib():
     return L
 
 
-EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper",
+EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_sync_check", "bprx_profile_enable",

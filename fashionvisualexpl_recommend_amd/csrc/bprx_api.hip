@@ -26,7 +26,7 @@ static void graph_drop(bprx_handle *h) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -115,6 +115,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     A(dalloc_zero((uint16_t **)&h->Wb, I * PS));
     A(dalloc_zero(&h->Ppair, MB * PS));
     A(dalloc_zero((uint16_t **)&h->Et, PS * D));
+    A(dalloc_zero((uint16_t **)&h->EtF, PS * D));
     A(dalloc_zero(&h->dEp, D * d + D));
     A(dalloc_zero(&h->part, (size_t)h->SK * D * PS));
     A(dalloc_zero(&h->qs, (size_t)4));
@@ -152,6 +153,22 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       }
     }
   }
+  // Touched-item list (sparse batches): when the batch touches few of the items, both projections run over the batch's
+  // distinct items only (the reference gathers 2B feature rows per step, VBPR.py:78; its own default is --batch_size 256,
+  // train_rec.py:23) instead of streaming all of F twice.  Per step: list mode iff 4B <= I (at most half of the rows);
+  // BPRX_LIST_MODE = 0 never / 1 per step / 2 always.
+  h->list_policy = vb ? 1 : 0;
+  if (const char *e = getenv("BPRX_LIST_MODE")) { const int v = atoi(e); h->list_policy = vb ? (v < 0 ? 0 : (v > 2 ? 2 : v)) : 0; }
+  if (h->list_policy) {
+    const size_t cap = 2 * MB < I ? 2 * MB : I;
+    if (dalloc_zero(&h->ilist, cap) != hipSuccess || dalloc_zero(&h->ilist_n, (size_t)1) != hipSuccess) {
+      snprintf(g_create_err, sizeof(g_create_err), "item list allocation failed");
+      free_scratch(h);
+      delete h;
+      return BPRX_E_NOMEM;
+    }
+  }
+  h->SK_step = h->SK;
   // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
   h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;   // per side: make_args
   if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
@@ -235,6 +252,7 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
   if (((uintptr_t)t->Gu | (uintptr_t)t->Gi | (uintptr_t)t->Tu | (uintptr_t)t->F | (uintptr_t)t->E) & 15)
     BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: table base pointers must be 16-byte aligned");
   h->t = *t;
+  h->et_valid = h->p_valid = false;
   graph_drop(h);                            // a captured step holds the old table pointers
   {
     const int rc = bprx_launch_tile_F(h);   // the projections read a tiled copy of the frozen F (made here, once)
@@ -243,6 +261,15 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
   h->bound = true;
   return BPRX_OK;
 }
+
+extern "C" int bprx_tables_dirty(bprx_handle *h) {
+  if (!h) return BPRX_E_INVALID;
+  h->et_valid = h->p_valid = false;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
+extern "C" int bprx_kernel_variant_safe(int ver, int nt, int mt, int rem) { return bprx_variant_safe(ver, nt, mt, rem); }
 
 extern "C" int bprx_set_hyper(bprx_handle *h, float lr, float reg) {
   if (!h) return BPRX_E_INVALID;
@@ -273,8 +300,9 @@ extern "C" int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32
   if (!user || !item || !x) BPRX_FAIL(h, BPRX_E_INVALID, "score_pairs: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (h->cfg.model == BPRX_MODEL_VBPR) {
+    if (h->p_valid) return bprx_launch_score(h, user, item, B, nullptr, 0, x, s);      // every item's projection is at hand
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
-    if ((rc = bprx_launch_proj_fwd(h, item, B, h->Ppair, s))) return rc;   // one projection row per pair
+    if ((rc = bprx_launch_proj_fwd(h, item, B, nullptr, 0, h->Ppair, s))) return rc;     // one projection row per pair
     return bprx_launch_score(h, user, item, B, h->Ppair, 1, x, s);
   }
   return bprx_launch_score(h, user, item, B, nullptr, 0, x, s);
@@ -288,21 +316,30 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
-  h->item_mode = h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items);
-  const bool fork_index = vb && !h->proj_fresh && h->side && h->side_mode == 2;
+  // list mode: both projections over the batch's distinct items only (needs the index pass BEFORE the forward projection)
+  h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 4 * B <= (int64_t)h->cfg.num_items));
+  h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
+  h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
+  const bool fork_index = vb && !h->list_mode && !h->proj_fresh && h->side && h->side_mode == 2;
   if (fork_index) {                                        // index pass (no dependence on P) beside the projection
     BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
     BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, h->side))) return rc;
     BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
   }
-  if (vb && !h->proj_fresh) {
+  if (h->list_mode) {
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
-    if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;  // P = F.[E|Bp] for every item
+    if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;              // counts + the distinct-item list
+    const int64_t bound = 2 * B < (int64_t)h->cfg.num_items ? 2 * B : (int64_t)h->cfg.num_items;
+    if (!h->p_valid &&                                                                   // P rows of the listed items only
+        (rc = bprx_launch_proj_fwd(h, h->ilist, bound, h->ilist_n, 1, h->P, s))) return rc;
+  } else if (vb && !h->proj_fresh) {
+    if ((rc = bprx_launch_cast_Et(h, s))) return rc;
+    if (!h->p_valid && (rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;  // every item
   }
   h->proj_fresh = false;
   if (fork_index) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
-  else if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
+  else if (!h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, h->cfg.lr, s))) return rc;             // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
@@ -319,9 +356,9 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, h->side))) return rc;
     BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
     h->side_pending = true;
-    if ((rc = bprx_launch_proj_bwd(h, s))) return rc;                                   // dE|dBp = F^T W
+    if ((rc = bprx_launch_proj_bwd(h, B, s))) return rc;                                // dE|dBp = F^T W
   } else {
-    if (vb && (rc = bprx_launch_proj_bwd(h, s))) return rc;
+    if (vb && (rc = bprx_launch_proj_bwd(h, B, s))) return rc;
     if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, s))) return rc;
   }
   h->pending_B = B;
@@ -334,7 +371,8 @@ extern "C" int bprx_step_project(bprx_handle *h, void *stream) {
   if (h->cfg.model != BPRX_MODEL_VBPR) return BPRX_OK;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = bprx_launch_cast_Et(h, s))) return rc;
-  if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;
+  if (!h->p_valid && (rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;
+  h->p_valid = true;
   h->proj_fresh = true;
   return BPRX_OK;
 }
@@ -414,8 +452,11 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   // (BPRX_GRAPH=1) The sgd step is a fixed sequence of ~11 launches whose arguments repeat from call to call (index
   // buffers, loss scalar, stream): it can be captured into a hipGraph once and replayed -- one launch per step.  Not for adam (lr_t changes every step), not while per-kernel profiling is
   // on, not on the legacy default stream (cannot be captured): those take the plain path.
+  // Nor with fp8 features (the [E|Bp] absmax slot alternates on the host: a replayed graph would reuse one slot and never
+  // clear it), nor when a derived image is still valid at capture time (the captured sequence would lack its refresh).
   const bool can_graph = h->graph_mode && h->cfg.optimizer == BPRX_OPT_SGD && !h->prof && stream != nullptr && !h->side &&
-                         h->bound && B > 0 && B <= h->cfg.max_batch && user && pos && neg && !h->proj_fresh && !h->pending_B;
+                         h->bound && B > 0 && B <= h->cfg.max_batch && user && pos && neg && !h->proj_fresh && !h->pending_B &&
+                         h->cfg.feat_dtype != BPRX_F_FP8 && !h->et_valid && !h->p_valid;
   if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
   hipStream_t s = (hipStream_t)stream;
   const bool same = h->graph_exec && h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg &&
@@ -465,9 +506,10 @@ extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *o
   if (u0 < 0 || u1 > h->cfg.num_users || u0 > u1 || !out) BPRX_FAIL(h, BPRX_E_INVALID, "score_block: bad user range [%d,%d)", u0, u1);
   if (u0 == u1) return BPRX_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (h->cfg.model == BPRX_MODEL_VBPR) {
+  if (h->cfg.model == BPRX_MODEL_VBPR && !h->p_valid) {   // P = F.[E|Bp] once per parameter state, not once per user block
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
-    if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, h->P, s))) return rc;
+    if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;
+    h->p_valid = true;
   }
   if (h->cfg.embed_k % 2 == 0 && h->cfg.embed_d % 2 == 0 && !getenv("BPRX_NAIVE_SCORE_BLOCK"))
     return bprx_launch_score_gemm(h, u0, u1, out, s);          // fp32 MFMA GEMM (K step 2)

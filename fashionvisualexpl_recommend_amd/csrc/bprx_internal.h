@@ -25,6 +25,8 @@ struct bprx_handle {
   double *loss_acc;               // [BPRX_DENSE_BLOCKS] per-block partial sums of ||E||^2+||Bp||^2 (k_dense_update)
   int dense_blocks;               // blocks of the last k_dense_update launch
   bool proj_fresh;                // bprx_step_project already ran for the coming step
+  bool et_valid;                  // the bf16/fp8 image Et matches the bound E/Bp (cleared by every dense update, bind, tables_dirty)
+  bool p_valid;                   // P holds the projections of ALL items for the bound E/Bp (bprx_score_block reuses it)
   bool fused_reduce;              // bprx_step: k_dense_update sums the split-K slabs itself (no k_reduce_parts)
   int32_t *errflag;               // device-side deferred error (index out of range)
   // VBPR projection state
@@ -35,6 +37,7 @@ struct bprx_handle {
   float *Ppair;                   // [max_batch][PS] projections for bprx_score_pairs
   void *Ft;                       // tiled copy of F (bf16 / fp8 features): 8-KB blocks of 32 items x 256 B, see k_tile_F
   void *Et;                       // bf16 [PS][D]: [E|Bp|0]^T, refreshed every step
+  void *EtF;                      // the same values in MFMA-fragment-major order (k_proj_fwd_rows), see k_cast_Et
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
@@ -51,6 +54,14 @@ struct bprx_handle {
   int32_t *seg_cursor;            // [1] bump allocator of segments
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
+  // touched-item list (sparse batches, 4B <= I): both projections run over the batch's DISTINCT items only
+  int list_policy;                // 0 never, 1 per step (4B <= I), 2 always (env BPRX_LIST_MODE)
+  int list_mode;                  // this step
+  int32_t *ilist;                 // [min(2*max_batch, I)] distinct items of the batch, in arrival order (k_row_count)
+  int32_t *ilist_n;               // [1] their number; reset by k_dense_update (the last list consumer of a step has run)
+  bool list_reset_cnt;            // list mode: k_cast_W_rows resets cntI (no exclusive-row fast path on the item side)
+  bool W_dirty;                   // the fp32 W table is not all-zero (left so by a dense fp32-feature step)
+  int SK_step;                    // split-K slabs written by this step's backward projection (<= SK)
   int num_cu;                     // compute units of the device (balanced forward grid)
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
@@ -123,5 +134,8 @@ int bprx_launch_score_gemm(bprx_handle *h, int32_t u0, int32_t u1, float *out, h
 // projection part (bprx_proj.hip)
 int bprx_launch_tile_F(bprx_handle *h);
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s);
-int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s);
-int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s);
+// rows == nullptr: items 0..nrows; else the listed items.  nrows_dev (device, optional): the actual row count (<= nrows, the
+// host-side bound the grid is sized for).  scatter: row t of the result goes to Pout[rows[t]] instead of Pout[t].
+int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_t *nrows_dev, int scatter, float *Pout,
+                         hipStream_t s);
+int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s);

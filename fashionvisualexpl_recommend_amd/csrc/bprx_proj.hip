@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ E, siz
 // same BYTE layout as the bf16 image with 128-wide chunks, so the forward kernels are shared).  Block (0,0) also
 // publishes qs[1] = 1 / (feat_scale * sE), the factor that turns the fp8 products back into P.
 __global__ __launch_bounds__(256) void k_cast_Et8(const float *__restrict__ E, const float *__restrict__ Bp,
-                                                  uint8_t *__restrict__ Et, int D, int d, int PS, float *__restrict__ qs,
-                                                  float feat_scale, int slot) {
+                                                  uint8_t *__restrict__ Et, uint8_t *__restrict__ EtF, int D, int d, int PS,
+                                                  float *__restrict__ qs, float feat_scale, int slot) {
   __shared__ float tile[64][17];
   const float amax = qs[2 + slot];                         // written by k_absmax just before; the other slot is cleared here
   const float sE = amax > 0.f ? 448.0f / amax : 1.0f;      // for the next step's k_absmax (no memset launch per step)
@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void k_cast_Et8(const float *__restrict__ E, c
   __syncthreads();
   for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
     const int nc = idx >> 6, kr = idx & 63, kk = k0 + kr, n = n0 + nc;
-    if (n < PS && kk < D) Et[((size_t)(kk >> 8) * PS + n) * 256 + (kk & 255)] = (uint8_t)f2e4m3(tile[kr][nc] * sE);
+    if (n < PS && kk < D) {
+      const uint8_t code = (uint8_t)f2e4m3(tile[kr][nc] * sE);
+      Et[((size_t)(kk >> 8) * PS + n) * 256 + (kk & 255)] = code;
+      // fragment-major twin (k_proj_fwd_rows): byte b = kk & 255 of chunk kk >> 8 -> k-step b >> 6, lane quarter (b >> 4) & 3
+      const int b = kk & 255;
+      EtF[(((((size_t)(kk >> 8) * 4 + (b >> 6)) * (PS >> 4) + (n >> 4)) * 64) + ((b >> 4) & 3) * 16 + (n & 15)) * 16 + (b & 15)] = code;
+    }
   }
 }
 
@@ -124,8 +130,11 @@ __global__ __launch_bounds__(256) void k_tile_F(const uint16_t *__restrict__ F, 
 
 // Et(n, k) = E[k][n] for n < d ; Bp[k] for n == d ; 0 above.  One block per (64 k-rows x 16 columns) tile, transposed
 // through LDS so that every Et row segment is written as 128 contiguous bytes.
+// EtF: the same values FRAGMENT-MAJOR for k_proj_fwd_rows -- element (n, k) at
+//   ((((k/128)*4 + (k%128)/32) * (PS/16) + n/16) * 64 + ((k%32)/8)*16 + n%16) * 8 + k%8 :
+// the 64 lanes x 8 elements of one (chunk, k-step, column tile) MFMA B fragment are 1 KB of contiguous bytes.
 __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, const float *__restrict__ Bp,
-                                                 uint16_t *__restrict__ Et, int D, int d, int PS) {
+                                                 uint16_t *__restrict__ Et, uint16_t *__restrict__ EtF, int D, int d, int PS) {
   __shared__ float tile[64][17];
   const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
   for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
@@ -137,7 +146,12 @@ __global__ __launch_bounds__(256) void k_cast_Et(const float *__restrict__ E, co
   __syncthreads();
   for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
     const int nc = idx >> 6, kr = idx & 63, kk = k0 + kr, n = n0 + nc;
-    if (n < PS && kk < D) Et[et_idx(n, kk, PS)] = f2bf(tile[kr][nc]);
+    if (n < PS && kk < D) {
+      const uint16_t v = f2bf(tile[kr][nc]);
+      Et[et_idx(n, kk, PS)] = v;
+      const int e = kk & 127;
+      EtF[(((((size_t)(kk >> 7) * 4 + (e >> 5)) * (PS >> 4) + (n >> 4)) * 64) + ((e >> 3) & 3) * 16 + (n & 15)) * 8 + (e & 7)] = v;
+    }
   }
 }
 
@@ -217,6 +231,139 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
         for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
       }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward over a ROW LIST (sparse batches: the batch's distinct items; bprx_score_pairs: one row per pair).  Few rows,
+// so the parallelism has to come from K: one NW-wave workgroup per MT*16 listed rows and NTW column tiles, the waves
+// split the k-chunks round-robin (wave w: chunks w, w+NW, ...).  Every wave loads its A fragments (feature rows of the
+// tiled F, gathered through the list) and its B fragments straight into MFMA operand order -- no two waves need the
+// same bytes, so nothing is staged through LDS and the loop has no barrier -- and the partial accumulators meet in LDS
+// in a fixed tree order (bit-reproducible).
+//   B comes from the FRAGMENT-MAJOR image EtF of [E|Bp]^T (k_cast_Et): the 64 x 16 B of one (chunk, k-step, column
+//   tile) fragment are contiguous in lane order, so a wave load is 1 KB of whole cache lines.  (From the chunk-major
+//   image the same fragment is 16 rows x 64 B: measured ~18 B/clk per CU through the vector L1 -- a workgroup that
+//   streams the whole 0.65-MB image took ~17 us whatever the row count.)
+//   NTW < NT (tiny launches: fewer row tiles than CUs): the column tiles are split over blockIdx.y, each workgroup then
+//   streams only its NTW/NT share of the image and the row tile's A bytes are re-read from L2 by its siblings.
+//   All feature fragments of a wave's chunk group are requested before the first MFMA (independent 16-B loads: the rows
+//   are random 8-KB rows of a table far larger than any cache, their round trips must overlap), the B fragments run
+//   one k-step ahead; scheduling fences keep hipcc from sinking the loads next to their MFMAs.
+// nrows_dev: the list length is only known on the device (k_row_count builds the list): the grid is sized for the
+// host-side bound `nrows`, surplus workgroups leave at once.  scatter: result row t goes to P[rows[t]].
+// ------------------------------------------------------------------------------------------------------------
+template <int NTW, int MT, int NW, bool F8>
+__global__ __launch_bounds__(NW * 64) void k_proj_fwd_rows(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
+                                                       int nrows, const int32_t *__restrict__ nrows_dev, int nitems, int D,
+                                                       const uint16_t *__restrict__ EtF, float *__restrict__ P, int PS,
+                                                       int32_t *errflag, const float *__restrict__ pscale, int scatter) {
+  extern __shared__ __attribute__((aligned(16))) float red_rows[];   // [NW/2 waves][NTW*4 registers][64 lanes]
+  // chunks per group: up to 16 A fragments in flight per lane where the register budget allows (128 per lane at 16 waves,
+  // 256 at 8; wide projections hold NTW*4 accumulators and 2*NTW*4 B fragments)
+  constexpr int CG = NW == 16 ? 2 : (MT == 1 ? (NTW <= 9 ? 4 : (NTW <= 13 ? 2 : 1)) : (MT == 2 ? 2 : 1));
+  constexpr int KS = KC / 32;
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
+  const int row0 = blockIdx.x * (MT * 16);
+  if (row0 >= nrows) return;                              // workgroup-uniform
+  const int NT = PS >> 4, nt0 = blockIdx.y * NTW;         // this workgroup's column tiles [nt0, nt0 + NTW) (clamped below)
+  // (readfirstlane: the wave index is uniform, which hipcc cannot prove from threadIdx -- chunk indices and the B offsets
+  //  derived from it then live in SGPRs instead of per-lane 64-bit address pairs)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const uint16_t *arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int t = row0 + mt * 16 + r;
+    if (t >= nrows) t = nrows - 1;                        // padding lanes re-read the last row; never stored
+    int item = rows ? rows[t] : t;
+    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+    arow[mt] = F + ft_row(item, D) + q * 8;
+  }
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nch = D / KC;
+  // fragment (c, ks, nt) of EtF: (((c*KS + ks)*NT + nt)*64 + lane)*8 units; column tiles past the end repeat the last
+  // one.  Byte offsets in 32 bits (the image is PS*D*2 <= 2.3 MB): uniform base + per-lane 32-bit offset loads.
+  const unsigned char *eb = reinterpret_cast<const unsigned char *>(EtF);
+  uint32_t boff[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) { const int n = nt0 + nt < NT ? nt0 + nt : NT - 1; boff[nt] = (uint32_t)(n * 64 + lane) * 16u; }
+  const uint32_t kstep = (uint32_t)NT * 1024u;            // bytes per (c, ks)
+  // wave w owns chunks w, w + NW, ...; a group = CG of them (clamped re-reads past the end, masked out of the sums)
+  for (int c0 = w; c0 < nch; c0 += NW * CG) {
+    i32x4_t a[CG][KS][MT];
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) {
+      int c = c0 + cg * NW;
+      c = c < nch ? c : c0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[cg][ks][mt] = *reinterpret_cast<const i32x4_t *>(arow[mt] + ((size_t)c << 12) + ks * 32);
+    }
+    i32x4_t b[2][NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) b[0][nt] = *reinterpret_cast<const i32x4_t *>(eb + ((uint32_t)(c0 * KS) * kstep + boff[nt]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < CG * KS; ++st) {
+      const int cg = st / KS, ks = st % KS;
+      if (st + 1 < CG * KS) {                               // next k-step's B fragments before this step's MFMAs
+        const int cg1 = (st + 1) / KS, ks1 = (st + 1) % KS;
+        int c1 = c0 + cg1 * NW;
+        c1 = c1 < nch ? c1 : c0;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          b[(st + 1) & 1][nt] = *reinterpret_cast<const i32x4_t *>(eb + ((uint32_t)(c1 * KS + ks1) * kstep + boff[nt]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c0 + cg * NW < nch) {                             // wave-uniform
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_frag<F8>(a[cg][ks][mt], b[st & 1][nt], acc[mt][nt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const float ps = F8 ? *pscale : 1.0f;
+  // pairwise tree over the waves (w += w + half, half = NW/2 .. 1): the same order every run
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+      if (w >= half && w < 2 * half) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) red_rows[(((w - half) * NTW + nt) * 4 + reg) * 64 + lane] = acc[mt][nt][reg];
+      }
+      __syncthreads();
+      if (w < half) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[mt][nt][reg] += red_rows[((w * NTW + nt) * 4 + reg) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (w == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {                 // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4)*4 + reg
+        const int t = row0 + mt * 16 + q * 4 + reg;
+        if (t < nrows) {
+          int o = t;
+          if (scatter) { o = rows[t]; if ((unsigned)o >= (unsigned)nitems) o = 0; }
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            if (nt0 + nt < NT) P[(size_t)o * PS + (nt0 + nt) * 16 + r] = acc[mt][nt][reg] * ps;
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -344,10 +491,16 @@ __device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t w, uint32_t &o0, uint32
 
 // F8: F holds fp8 codes (1 byte per element): the tile loads move half the bytes and the codes are widened to bf16 on
 // the way into LDS (W stays bf16); the slabs then hold (F*feat_scale)^T W and are rescaled where they are summed.
-template <int NT, int BTV, int NW, int PD, bool F8>
+// ROWS: the sum runs over the LISTED items only (sparse batches): tile row p is item rows[p], its feature pieces are
+// gathered from the tiled F (256 contiguous bytes per item and 128-column block), Wb is the COMPACT image (row p = list
+// position p), the list length comes from the device (*nrows_dev; `nrows` is the host-side bound) and the item splits are
+// cut from it here.
+template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS = false>
 __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
                                                           const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
-                                                          int rows_per_split, int descend, int xcd_map) {
+                                                          int rows_per_split, int descend, int xcd_map,
+                                                          const int32_t *__restrict__ rows = nullptr,
+                                                          const int32_t *__restrict__ nrows_dev = nullptr) {
   constexpr int NTH = NW * 64, MC = NW * 32;         // threads, feature columns per workgroup
   constexpr int ESZ = F8 ? 1 : 2;                    // bytes per feature element in HBM
   constexpr int FCH = MC * ESZ / 16;                 // 16-B pieces per F tile row (HBM side)
@@ -373,6 +526,11 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
   }
   const int m0 = bx * MC;
   const int Deq = D * ESZ / 2, m0q = m0 * ESZ / 2;   // row width / first column in 16-bit units (tiled F addressing)
+  if constexpr (ROWS) {
+    const int n = *nrows_dev;
+    nrows = n < nrows ? n : nrows;
+    rows_per_split = ((nrows + (int)gridDim.y - 1) / (int)gridDim.y + BTV - 1) / BTV * BTV;
+  }
   const int tbeg = by * rows_per_split;
   int tend = tbeg + rows_per_split;
   if (tend > nrows) tend = nrows;
@@ -395,8 +553,16 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
     /* tiled F: the tile is (BTV/32) x CBK contiguous 8-KB blocks; piece p lies in block p >> 9 at 16-B slot p & 511 */ \
     _Pragma("unroll") for (int x = 0; x < FPT; ++x) {                                                                    \
       const int pp = threadIdx.x + x * NTH, blk = pp >> 9;                                                               \
-      const size_t bidx = (size_t)((t0 >> 5) + blk / CBK) * (Deq >> 7) + (m0q >> 7) + blk % CBK;                         \
-      freg[ST][x] = *reinterpret_cast<const uint4 *>(F + bidx * 4096 + (size_t)(pp & 511) * 8);                          \
+      if constexpr (ROWS) {                                                                                              \
+        int tp = t0 + (blk / CBK) * 32 + ((pp & 511) >> 4);                                                              \
+        tp = tp < tend ? tp : tend - 1;                                                                                  \
+        const int item = rows[tp];                                                                                       \
+        freg[ST][x] = *reinterpret_cast<const uint4 *>(F + ft_row(item, Deq) + (size_t)((m0q >> 7) + blk % CBK) * 4096 + \
+                                                       (size_t)(pp & 15) * 8);                                           \
+      } else {                                                                                                           \
+        const size_t bidx = (size_t)((t0 >> 5) + blk / CBK) * (Deq >> 7) + (m0q >> 7) + blk % CBK;                       \
+        freg[ST][x] = *reinterpret_cast<const uint4 *>(F + bidx * 4096 + (size_t)(pp & 511) * 8);                        \
+      }                                                                                                                  \
     }                                                                                                                    \
     _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
       int idx = threadIdx.x + x * NTH;                                                                                   \
@@ -936,33 +1102,72 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ 
 // fp32 feature path (small, reference-precision configs): fp64 accumulate on the vector ALU.
 // ------------------------------------------------------------------------------------------------------------
 // one wave per row; lane n owns output columns n, n+64, ...; F[t][k] is a wave-wide broadcast, E rows are coalesced.
+// (nrows_dev / scatter: as k_proj_fwd_rows)
 __global__ __launch_bounds__(256) void k_proj_fwd_f32(const float *__restrict__ F, const int32_t *__restrict__ rows,
-                                                      int nrows, int nitems, int D, const float *__restrict__ E,
-                                                      const float *__restrict__ Bp, int d, float *__restrict__ P, int PS,
-                                                      int32_t *errflag) {
+                                                      int nrows, const int32_t *__restrict__ nrows_dev, int scatter, int nitems,
+                                                      int D, const float *__restrict__ E, const float *__restrict__ Bp, int d,
+                                                      float *__restrict__ P, int PS, int32_t *errflag) {
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
   if (t >= nrows) return;
   int item = rows ? rows[t] : t;
   if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
   const float *f = F + (size_t)item * D;
+  const size_t o = scatter ? (size_t)item : (size_t)t;
   for (int n = lane; n <= d; n += 64) {
     double acc = 0.0;
     if (n < d) for (int kk = 0; kk < D; ++kk) acc += (double)f[kk] * (double)E[(size_t)kk * d + n];
     else for (int kk = 0; kk < D; ++kk) acc += (double)f[kk] * (double)Bp[kk];
-    P[(size_t)t * PS + n] = (float)acc;
+    P[o * PS + n] = (float)acc;
   }
 }
 
 // one thread per output (k, n), n <= d; W rows are coalesced over n, F[t][k] is a broadcast.
+// rows != nullptr: the sum runs over the listed items only (list mode; W rows are indexed by item id in both forms)
 __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ F, int nrows, int D,
-                                                      const float *__restrict__ W, int d, int PS, float *__restrict__ dEp) {
+                                                      const float *__restrict__ W, int d, int PS, float *__restrict__ dEp,
+                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev) {
   const int kk = blockIdx.x;
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
   for (int n = threadIdx.x; n <= d; n += 256) {
     double acc = 0.0;
-    for (int t = 0; t < nrows; ++t) acc += (double)F[(size_t)t * D + kk] * (double)W[(size_t)t * PS + n];
+    if (rows) {
+      for (int t = 0; t < nrows; ++t) {
+        const int item = rows[t];
+        acc += (double)F[(size_t)item * D + kk] * (double)W[(size_t)item * PS + n];
+      }
+    } else {
+      for (int t = 0; t < nrows; ++t) acc += (double)F[(size_t)t * D + kk] * (double)W[(size_t)t * PS + n];
+    }
     if (n < d) dEp[(size_t)kk * d + n] = (float)acc;
     else dEp[(size_t)D * d + kk] = (float)acc;
   }
+}
+
+// List mode, after k_triplet_grad: the fp32 W rows of the listed items (accumulated by item id) become the COMPACT bf16
+// image the backward MFMA reads (row p = list position p; Wc == nullptr: fp32 features, W is read in place and this
+// kernel runs AFTER the backward projection), the W rows return to zero for the next step, and -- when nobody else does
+// it (no exclusive-row fast path) -- the row multiplicities are reset.  One float4 per thread.
+__global__ __launch_bounds__(256) void k_cast_W_rows(float *__restrict__ W, uint16_t *__restrict__ Wc, int PS,
+                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev,
+                                                     int bound, int32_t *__restrict__ cntI) {
+  const int per = PS / 4;
+  int n = *nrows_dev;
+  n = n < bound ? n : bound;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int p = (int)(e / per), c4 = (int)(e % per);
+  if (p >= n) return;
+  const int item = rows[p];
+  float4 *src = reinterpret_cast<float4 *>(W + (size_t)item * PS) + c4;
+  if (Wc) {
+    const float4 v = *src;
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    reinterpret_cast<uint2 *>(Wc + (size_t)p * PS)[c4] = pk;
+  }
+  *src = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cntI && c4 == 0) cntI[item] = 0;
 }
 
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
@@ -1025,6 +1230,42 @@ void launch_v8_rt(int nt, bprx_handle *h, const int32_t *rows, int64_t nrows, fl
   }
 }
 
+// row-list forward (k_proj_fwd_rows): column split / row tiles per workgroup by launch size and register budget
+template <int NT>
+void launch_fwd_rows(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_t *nrows_dev, int scatter, float *Pout,
+                     hipStream_t s) {
+  const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
+  const int Deq = f8 ? h->cfg.feat_dim / 2 : h->cfg.feat_dim;
+  const float *pscale = h->qs + 1;
+  const int64_t tiles = (nrows + 15) / 16;
+  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+  int mt = 1;
+  if (NT <= 5 && tiles > 8 * (int64_t)ncu) mt = 4;
+  else if (NT <= 9 && tiles > 2 * (int64_t)ncu) mt = 2;
+  if (const char *e = getenv("BPRX_ROWS_MT")) { const int v = atoi(e); if (v == 1 || (v == 2 && NT <= 9) || (v == 4 && NT <= 5)) mt = v; }
+  // tiny launches (row tiles x column tiles fit the chip twice): one column tile per workgroup, 16 waves split K
+  bool split = NT > 1 && tiles * NT <= 2 * (int64_t)ncu;
+  if (const char *e = getenv("BPRX_ROWS_SPLIT")) split = NT > 1 && atoi(e) != 0;
+#define ROWS_LAUNCH(NTW_, MT_, NW_, F8_, GY_)                                                                            \
+  do {                                                                                                                   \
+    auto kfn = k_proj_fwd_rows<NTW_, MT_, NW_, F8_>;                                                                     \
+    const size_t lds = (size_t)NTW_ * 2048 * NW_ / 4;                                                                    \
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((tiles + MT_ - 1) / MT_), (unsigned)(GY_)), dim3(NW_ * 64), lds, s,          \
+                       (const uint16_t *)h->Ft, rows, (int)nrows, nrows_dev, h->cfg.num_items, Deq,                      \
+                       (const uint16_t *)h->EtF, Pout, h->PS, h->errflag, pscale, scatter);                              \
+  } while (0)
+  if (split) { if (f8) ROWS_LAUNCH(1, 1, 16, true, NT); else ROWS_LAUNCH(1, 1, 16, false, NT); return; }
+  if constexpr (NT <= 5) {
+    if (mt == 4) { if (f8) ROWS_LAUNCH(NT, 4, 8, true, 1); else ROWS_LAUNCH(NT, 4, 8, false, 1); return; }
+  }
+  if constexpr (NT <= 9) {
+    if (mt == 2) { if (f8) ROWS_LAUNCH(NT, 2, 8, true, 1); else ROWS_LAUNCH(NT, 2, 8, false, 1); return; }
+  }
+  if (f8) ROWS_LAUNCH(NT, 1, 8, true, 1); else ROWS_LAUNCH(NT, 1, 8, false, 1);
+#undef ROWS_LAUNCH
+}
+
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   constexpr int MTD = NT <= 9 ? 2 : 1;
@@ -1082,6 +1323,25 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   else if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, true>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1, pscale);
   else if (MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1, false>), grid, dim3(256), 0, s, FWD_ARGS, stg, pscale);
   else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, false>), grid, dim3(256), 0, s, FWD_ARGS, stg, pscale);
+  return 0;
+}
+
+// backward over the touched-item list (list mode): v3 kernel in ROWS form, 2 tiles in flight; `bound` = host-side bound of
+// the list length
+template <int NT>
+int launch_bwd_rows(bprx_handle *h, int64_t bound, hipStream_t s) {
+  const int D = h->cfg.feat_dim;
+  const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
+  const bool w8 = D % 256 == 0 || f8;
+  dim3 g3(D / (w8 ? 256 : 128), h->SK_step);
+#define BWDR_LAUNCH(NW_, F8_)                                                                                            \
+  hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32, NW_, 2, F8_, true>), g3, dim3(NW_ * 64), 0, s, (const uint16_t *)h->Ft,  \
+                     (int)bound, D, (const uint16_t *)h->Wb, h->PS, h->part, 0, 0, 1, (const int32_t *)h->ilist,        \
+                     (const int32_t *)h->ilist_n)
+  if (f8) BWDR_LAUNCH(8, true);
+  else if (w8) BWDR_LAUNCH(8, false);
+  else BWDR_LAUNCH(4, false);
+#undef BWDR_LAUNCH
   return 0;
 }
 
@@ -1174,6 +1434,8 @@ int bprx_launch_tile_F(bprx_handle *h) {
 
 int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
   if (h->cfg.feat_dtype == BPRX_F_FP32) return BPRX_OK;
+  if (h->et_valid) return BPRX_OK;                      // E / Bp unchanged since the image was made
+  h->et_valid = true;
   const int D = h->cfg.feat_dim;
   BprxProfScope ps(h, BPRX_PHASE_CAST_ET, s);
   dim3 grid((D + 63) / 64, h->PS / 16);
@@ -1182,54 +1444,93 @@ int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
     h->qs_slot ^= 1;
     hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, h->t.E, (size_t)D * h->cfg.embed_d, h->t.Bp, (size_t)D,
                        (uint32_t *)h->qs + 2 + slot);
-    hipLaunchKernelGGL(k_cast_Et8, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint8_t *)h->Et, D, h->cfg.embed_d, h->PS, h->qs,
-                       h->cfg.feat_scale, slot);
+    hipLaunchKernelGGL(k_cast_Et8, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint8_t *)h->Et, (uint8_t *)h->EtF, D,
+                       h->cfg.embed_d, h->PS, h->qs, h->cfg.feat_scale, slot);
     BPRX_LAUNCH_CHECK(h, "k_cast_Et8");
     return BPRX_OK;
   }
-  hipLaunchKernelGGL(k_cast_Et, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint16_t *)h->Et, D, h->cfg.embed_d, h->PS);
+  hipLaunchKernelGGL(k_cast_Et, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint16_t *)h->Et, (uint16_t *)h->EtF, D,
+                     h->cfg.embed_d, h->PS);
   BPRX_LAUNCH_CHECK(h, "k_cast_Et");
   return BPRX_OK;
 }
 
-int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
+int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_t *nrows_dev, int scatter, float *Pout,
+                         hipStream_t s) {
   if (nrows <= 0) return BPRX_OK;
   BprxProfScope ps(h, BPRX_PHASE_PROJ_FWD, s);
   if (h->cfg.feat_dtype != BPRX_F_FP32) {
     const int NT = h->PS / 16;
+    if (rows) {                                          // row list: K split over the waves of one workgroup per 16-64 rows
+#define CALL(N) launch_fwd_rows<N>(h, rows, nrows, nrows_dev, scatter, Pout, s)
+      NT_SWITCH(NT, CALL)
+#undef CALL
+      BPRX_LAUNCH_CHECK(h, "k_proj_fwd_rows");
+      return BPRX_OK;
+    }
 #define CALL(N) launch_fwd_nt<N>(h, rows, nrows, Pout, s)
     NT_SWITCH(NT, CALL)
 #undef CALL
     BPRX_LAUNCH_CHECK(h, "k_proj_fwd_bf16");
   } else {
     dim3 grid((unsigned)((nrows + 3) / 4));
-    hipLaunchKernelGGL(k_proj_fwd_f32, grid, dim3(256), 0, s, (const float *)h->t.F, rows, (int)nrows, h->cfg.num_items,
-                       h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
+    hipLaunchKernelGGL(k_proj_fwd_f32, grid, dim3(256), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
+                       h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
     BPRX_LAUNCH_CHECK(h, "k_proj_fwd_f32");
   }
   return BPRX_OK;
 }
 
-int bprx_launch_proj_bwd(bprx_handle *h, hipStream_t s) {
+// B: batch size of the step (bounds the touched-item list in list mode)
+int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s) {
   const int D = h->cfg.feat_dim, d = h->cfg.embed_d, I = h->cfg.num_items;
+  const int64_t bound = 2 * B < (int64_t)I ? 2 * B : (int64_t)I;     // list mode: at most 2B distinct items
+  h->SK_step = h->SK;
   if (h->cfg.feat_dtype != BPRX_F_FP32) {
     const int NT = h->PS / 16;
-    {
+    if (h->list_mode) {
+      // few rows: fewer item splits (each split writes a D x PS fp32 slab that the dense update reads back)
+      int sk = (int)((bound + 127) / 128);
+      h->SK_step = sk < 1 ? 1 : (sk > h->SK ? h->SK : sk);
+      {
+        BprxProfScope pc(h, BPRX_PHASE_CAST_W, s);
+        const int64_t n4 = bound * (h->PS / 4);
+        hipLaunchKernelGGL(k_cast_W_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, h->PS,
+                           (const int32_t *)h->ilist, (const int32_t *)h->ilist_n, (int)bound, h->list_reset_cnt ? h->cntI : nullptr);
+      }
+      {
+        BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
+#define CALL(N) launch_bwd_rows<N>(h, bound, s)
+        NT_SWITCH(NT, CALL)
+#undef CALL
+      }
+      BPRX_LAUNCH_CHECK(h, "k_proj_bwd_bf16_v3<rows>");
+    } else {
       BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
 #define CALL(N) launch_bwd_nt<N>(h, s)
       NT_SWITCH(NT, CALL)
 #undef CALL
+      BPRX_LAUNCH_CHECK(h, "k_proj_bwd_bf16");
     }
-    BPRX_LAUNCH_CHECK(h, "k_proj_bwd_bf16");
     if (h->fused_reduce) return BPRX_OK;              // k_dense_update sums the slabs (bprx_step, bf16 path)
     const size_t n = (size_t)D * h->PS;
     BprxProfScope ps(h, BPRX_PHASE_REDUCE, s);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK, D, d, h->PS, h->dEp,
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->part, h->SK_step, D, d, h->PS, h->dEp,
                        h->cfg.feat_dtype == BPRX_F_FP8 ? 1.0f / h->cfg.feat_scale : 1.0f);
     BPRX_LAUNCH_CHECK(h, "k_reduce_parts");
   } else {
-    BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
-    hipLaunchKernelGGL(k_proj_bwd_f32, dim3(D), dim3(256), 0, s, (const float *)h->t.F, I, D, h->W, d, h->PS, h->dEp);
+    {
+      BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
+      hipLaunchKernelGGL(k_proj_bwd_f32, dim3(D), dim3(256), 0, s, (const float *)h->t.F, h->list_mode ? (int)bound : I, D, h->W, d,
+                         h->PS, h->dEp, h->list_mode ? (const int32_t *)h->ilist : (const int32_t *)nullptr,
+                         h->list_mode ? (const int32_t *)h->ilist_n : (const int32_t *)nullptr);
+    }
+    if (h->list_mode) {                                 // W rows back to zero (the dense form memsets W at the next step)
+      BprxProfScope pc(h, BPRX_PHASE_CAST_W, s);
+      const int64_t n4 = bound * (h->PS / 4);
+      hipLaunchKernelGGL(k_cast_W_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->W, (uint16_t *)nullptr, h->PS,
+                         (const int32_t *)h->ilist, (const int32_t *)h->ilist_n, (int)bound, h->list_reset_cnt ? h->cntI : nullptr);
+    }
     BPRX_LAUNCH_CHECK(h, "k_proj_bwd_f32");
   }
   return BPRX_OK;

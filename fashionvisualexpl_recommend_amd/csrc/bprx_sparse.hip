@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
                                                    const int32_t *__restrict__ neg, int64_t B, int U, int I,
                                                    int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI,
                                                    int32_t *__restrict__ rank, int32_t *__restrict__ seg_cursor,
-                                                   uint4 *__restrict__ zero16, size_t nzero16) {
+                                                   uint4 *__restrict__ zero16, size_t nzero16,
+                                                   int32_t *__restrict__ ilist, int32_t *__restrict__ ilist_n, int ilist_cap) {
   // housekeeping that would otherwise be two hipMemsetAsync launches (5-6 us each on the trace): the segment cursor, and
   // the bf16 W image of the previous step (consumed by its backward projection), re-zeroed for k_item_seg
   if (seg_cursor && blockIdx.x == 0 && threadIdx.x == 0) *seg_cursor = 0;
@@ -124,8 +125,34 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
   const bool valid = b < B;
   const int u = valid ? clamp_quiet(user[b], U) : 0, i = valid ? clamp_quiet(pos[b], I) : 0, j = valid ? clamp_quiet(neg[b], I) : 0;
   if (valid && doU) atomicAdd(cntU + u, 1);
-  if (!rank) {
+  if (!rank && !ilist) {
     if (valid && doI) { atomicAdd(cntI + i, 1); atomicAdd(cntI + j, 1); }
+    return;
+  }
+  if (!rank) {
+    // List mode (sparse batches): the occurrence that finds its item's count at zero appends the item to the list of
+    // the batch's distinct items.  The appends of a workgroup are prefix-summed and take ONE atomic on the list cursor.
+    __shared__ int lw[4], lbase;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bool ai = false, aj = false;
+    if (valid) {
+      ai = atomicAdd(cntI + i, 1) == 0;
+      aj = atomicAdd(cntI + j, 1) == 0;                   // i == j: the second add returns 1
+    }
+    const unsigned long long mi = __ballot(ai), mj = __ballot(aj);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int pre = __popcll(mi & below) + __popcll(mj & below);
+    if (lane == 0) lw[w] = __popcll(mi) + __popcll(mj);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = lw[0] + lw[1] + lw[2] + lw[3];
+      lbase = tot ? atomicAdd(ilist_n, tot) : 0;
+    }
+    __syncthreads();
+    int at = lbase + pre;
+    for (int q = 0; q < w; ++q) at += lw[q];
+    if (ai) { if (at < ilist_cap) ilist[at] = i; ++at; }
+    if (aj) { if (at < ilist_cap) ilist[at] = j; }
     return;
   }
   // Ranks: the workgroup's 512 occurrences are first counted per item in an LDS hash table (LDS atomics), then ONE global
@@ -489,8 +516,9 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
                                                       float *mBp, float *vBp, const float *__restrict__ dEp,
                                                       const float *__restrict__ part, int SK, int D, int d, int PS, int adam,
                                                       float lr_t, float reg, float b1, float b2, float eps,
-                                                      double *__restrict__ sqpart, float gscale) {
+                                                      double *__restrict__ sqpart, float gscale, int32_t *__restrict__ ilist_n) {
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  if (ilist_n && blockIdx.x == 0 && threadIdx.x == 0) *ilist_n = 0;     // every consumer of this step's item list has run
   double sq = 0.0;
   const size_t total = (size_t)D * PS;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -923,13 +951,15 @@ int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_
 // projection (bprx_step_begin)
 int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
   SparseArgs a = make_args(h, h->P);
-  if (h->fast_rows || h->item_mode) {
+  if (h->fast_rows || h->item_mode || h->list_mode) {
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
     const bool zw = h->item_mode && a.d && h->cfg.feat_dtype != BPRX_F_FP32;      // bf16 W image: rows of untouched items
+    const int64_t cap = 2 * B < (int64_t)a.I ? 2 * B : (int64_t)a.I;
     hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI,
-                       a.fastU, a.fastI, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
+                       a.fastU, (a.fastI || h->list_mode) ? 1 : 0, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
                        h->item_mode ? h->seg_cursor : (int32_t *)nullptr, (uint4 *)(zw ? h->Wb : nullptr),
-                       zw ? (size_t)a.I * a.PS * sizeof(uint16_t) / 16 : (size_t)0);
+                       zw ? (size_t)a.I * a.PS * sizeof(uint16_t) / 16 : (size_t)0,
+                       h->list_mode ? h->ilist : (int32_t *)nullptr, h->ilist_n, (int)cap);
   }
   if (h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
@@ -948,8 +978,12 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   // W (fp32) must be all-zero here.  bf16 features: k_cast_W (backward variants >= 8) re-zeroes it while converting and
   // k_item_seg re-zeroes the rows it folds in, so only the remaining combinations need the memset.
   const bool bf = h->cfg.feat_dtype != BPRX_F_FP32;     // bf16 W image (bf16 and fp8 features)
-  if (a.d && (!bf || (!h->item_mode && h->bwd_variant < 8)))
+  // dense form with fp32 features (or the fp32-W backward variants): W is consumed in place and cleared here, at the
+  // next step; list mode returns its rows to zero itself (k_cast_W_rows) and only needs the memset after such a step
+  const bool leaves_dirty = a.d && !h->list_mode && (!bf || (!h->item_mode && h->bwd_variant < 8));
+  if (leaves_dirty || (a.d && h->W_dirty))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
+  h->W_dirty = leaves_dirty;
   if (h->item_mode) DISPATCH_G(G, vec, k_triplet_grad_seg, grid_for(B, G), s, a, u, i, j, B);
   else DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
@@ -1028,9 +1062,11 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   // fp8 features: the slabs hold (F*feat_scale)^T W; an all-reduced dEp was already rescaled by k_reduce_parts
   const float gscale = (part && h->cfg.feat_dtype == BPRX_F_FP8) ? 1.0f / h->cfg.feat_scale : 1.0f;
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
-                     h->t.v_Bp, h->dEp, part, h->SK, h->cfg.feat_dim, h->cfg.embed_d, h->PS,
+                     h->t.v_Bp, h->dEp, part, h->SK_step, h->cfg.feat_dim, h->cfg.embed_d, h->PS,
                      h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg, h->cfg.beta1, h->cfg.beta2,
-                     h->cfg.epsilon, h->loss_acc, gscale);
+                     h->cfg.epsilon, h->loss_acc, gscale, h->ilist_n);
+  h->et_valid = false;                                  // E / Bp move: the bf16 / fp8 image and the projections are stale
+  h->p_valid = false;
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
   return BPRX_OK;
 }

@@ -104,6 +104,11 @@ class Engine:
         self.t = t
         return self
 
+    def tables_dirty(self):
+        """Call after writing any bound table from outside the library (bprx_tables_dirty): the handle reuses images
+        derived from E/Bp (their bf16/fp8 copy, the item projections) until a step changes them."""
+        _ffi.check(self.h, self.lib.bprx_tables_dirty(self.h))
+
     def params(self):
         return {n: self.t[n] for n in PARAM_NAMES if self.t.get(n) is not None}
 

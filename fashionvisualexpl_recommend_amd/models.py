@@ -119,6 +119,7 @@ class BPRMF(RecommenderModel):
                 self.engine.adam_step = v
             else:
                 self.engine.t[n].copy_(v)
+        self.engine.tables_dirty()                      # the handle caches images derived from E/Bp
 
     def weights_path(self, epoch):
         rec = getattr(self.params, "rec", self.model_kind)

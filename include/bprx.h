@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BPRX_ABI_VERSION 3
+#define BPRX_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define BPRX_API __attribute__((visibility("default")))
@@ -108,6 +108,12 @@ BPRX_API const char *bprx_last_error(const bprx_handle *h); /* h == NULL: error 
    caller's F is not read again until the next bprx_bind_tables and may be released.
    A handle is not thread-safe; all other entry points only enqueue work on the stream they are given. */
 BPRX_API int bprx_bind_tables(bprx_handle *h, const bprx_tables *t);
+/* The bound tables stay owned by the caller, who may write them between calls (restoring a snapshot: the reference
+   deep-copies / checkpoints the whole model, BPRMF.py:156-160,177-179).  The handle keeps images DERIVED from them across
+   calls -- the bf16/fp8 image of [E|Bp]^T and the item projections P = F.[E|Bp] that bprx_score_block / bprx_score_pairs
+   reuse until a step changes E/Bp -- so after writing any bound table from outside the library call bprx_tables_dirty()
+   before the next library call.  (bprx_bind_tables implies it.) */
+BPRX_API int bprx_tables_dirty(bprx_handle *h);
 BPRX_API int bprx_set_hyper(bprx_handle *h, float lr, float reg);           /* train_rec.py:69 (args.reg = reg) */
 BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations);         /* optimizer.iterations (resume) */
 BPRX_API int64_t bprx_get_adam_step(const bprx_handle *h);
@@ -170,7 +176,7 @@ BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out
 enum {
   BPRX_PHASE_CAST_ET = 0, BPRX_PHASE_PROJ_FWD = 1, BPRX_PHASE_TRIPLET = 2, BPRX_PHASE_PROJ_BWD = 3,
   BPRX_PHASE_REDUCE = 4, BPRX_PHASE_APPLY = 5, BPRX_PHASE_DENSE = 6, BPRX_PHASE_LOSS = 7, BPRX_PHASE_ITEM_SEG = 8,
-  BPRX_PHASE_SEG_ALLOC = 9, BPRX_PHASE_ROW_COUNT = 10, BPRX_PHASE_COUNT = 11
+  BPRX_PHASE_SEG_ALLOC = 9, BPRX_PHASE_ROW_COUNT = 10, BPRX_PHASE_CAST_W = 11, BPRX_PHASE_COUNT = 12
 };
 BPRX_API int bprx_profile_enable(bprx_handle *h, int on);
 BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);
@@ -184,6 +190,13 @@ BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);
 BPRX_API int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, const int64_t *train_ptr,
                              const int32_t *train_items, const int64_t *eval_ptr, const int32_t *eval_items, int32_t K,
                              double *out, void *stream);
+
+/* Build-time table of the software-pipelined forward-projection instantiations that hipcc compiled free of scratch,
+   spills and stray AGPR use (only those are ever launched; every other shape falls back to the plain kernel).
+   ver 6 / 8 = pipelined kernel generation, nt = column tiles, mt = row tiles per wave (ver 6) or 8 (ver 8),
+   rem = ablation id (ver 6) / fp8 flag (ver 8).  Returns 1 / 0.  For the test-suite, which runs every listed
+   instantiation against the plain kernel. */
+BPRX_API int bprx_kernel_variant_safe(int ver, int nt, int mt, int rem);
 
 /* Synchronise `stream` and report deferred device-side errors (index out of range). */
 BPRX_API int bprx_sync_check(bprx_handle *h, void *stream);

@@ -1,7 +1,9 @@
-"""BASELINE.json configs[1] at FULL size (VBPR k=d=64, D=4096, 100K users x 50K items, bf16, B=65 536) and the
-configs[2] per-GPU shard (BPRMF k=128, 625K x 1M): the oracle cannot run these in seconds, so the HIP path is checked
-through size-independent properties and against an independent torch fp32 recomputation of the SAME step on the device
-(torch is the checker here, never the product path)."""
+"""BASELINE.json configs[1], [3] (per-GPU shard) and [4] at FULL size -- VBPR k=d=64 bf16 100K x 50K; VBPR k=d=128 bf16
+250K x 62.5K (the c4shard shape: the 9-tile forward, the 8-wave backward with three tiles in flight); VBPR k=d=256 fp8
+(17 column tiles, column-range forward passes, fp8 feature table) -- and the configs[2] per-GPU shard (BPRMF k=128,
+625K x 1M): the oracle cannot run these in seconds, so the HIP path is checked through size-independent properties and
+against an independent torch fp32 recomputation of the SAME step on the device with the same operand rounding (torch is
+the checker here, never the product path).  Reference: VBPR.py:59-144, BPRMF.py:55-125."""
 import numpy as np
 import pytest
 import torch
@@ -16,17 +18,9 @@ def _state(workload):
     return w, dev, bench.make_state(w, dev, 77, torch)
 
 
-def test_c2_full_size_step_against_torch_fp32():
-    from fashionvisualexpl_recommend_amd.engine import Engine, PhiloxSampler
-    w, dev, t = _state("c2")
-    U, I, k, d, D, B = w["U"], w["I"], w["k"], w["d"], w["D"], w["B"]
-    lr, reg = 1e-3, 1e-4
-    g = torch.Generator(device=dev); g.manual_seed(5)
-    t["Bi"] = torch.randn(I, generator=g, device=dev) * 0.01
-    before = {n: v.clone() for n, v in t.items() if n != "F"}
-    eng = Engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype="bf16",
-                 optimizer="sgd", lr=lr, reg=reg, max_batch=B).bind(**t)
-    # ---- sampler properties at full size: positives are training interactions, negatives are not ----
+def _sampler_properties(U, I, B, dev, g):
+    """positives are training interactions, negatives are not; the stream is stateless"""
+    from fashionvisualexpl_recommend_amd.engine import PhiloxSampler
     npu = 20
     items = torch.randint(I, (U, npu), generator=g, device=dev, dtype=torch.int32).sort(dim=1).values
     indptr = torch.arange(U + 1, device=dev, dtype=torch.int64) * npu
@@ -39,13 +33,37 @@ def test_c2_full_size_step_against_torch_fp32():
     assert int(u.min()) >= 0 and int(u.max()) < U and int(j.min()) >= 0 and int(j.max()) < I
     u2, i2, j2 = s.sample(B, first=0)
     assert torch.equal(u, u2) and torch.equal(i, i2) and torch.equal(j, j2)          # stateless: same slice, same triplets
+    return u, i, j
 
-    # ---- independent fp32 recomputation of the step (same bf16 operand rounding, fp32 everywhere else) ----
+
+@pytest.mark.parametrize("workload", ["c2", "c4shard", "c5"])
+def test_vbpr_full_size_step_against_torch_fp32(workload):
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    w, dev, t = _state(workload)
+    U, I, k, d, D, B = w["U"], w["I"], w["k"], w["d"], w["D"], w["B"]
+    fp8 = w["dtype"] == "fp8"
+    lr, reg = 1e-3, 1e-4
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    t["Bi"] = torch.randn(I, generator=g, device=dev) * 0.01
+    before = {n: v.clone() for n, v in t.items() if n != "F"}
+    eng = Engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype=w["dtype"],
+                 optimizer="sgd", lr=lr, reg=reg, max_batch=B).bind(**t)
+    u, i, j = _sampler_properties(U, I, B, dev, g)
+
+    # ---- independent fp32 recomputation of the step: the SAME operand rounding (bf16 / e4m3 operands of the two
+    # projections), fp32 (matmuls) and fp64 (scatter sums) everywhere else ----
     ul, il, jl = u.long(), i.long(), j.long()
     F = t["F"]
-    Eq = torch.cat([before["E"], before["Bp"][:, None]], 1).to(torch.bfloat16).float()           # [D, d+1]
+    EB = torch.cat([before["E"], before["Bp"][:, None]], 1)                                       # [D, d+1]
+    if fp8:
+        sE = torch.tensor(448.0, device=dev) / EB.abs().max()                                     # k_absmax / k_cast_Et8
+        Eq = (EB * sE).to(torch.float8_e4m3fn).float() / sE
+        frow = lambda idx: F[idx].float() / 448.0                                                 # codes of f * 448
+    else:
+        Eq = EB.to(torch.bfloat16).float()
+        frow = lambda idx: F[idx].float()
     touched = torch.unique(torch.cat([il, jl]))
-    Pt = F[touched].float() @ Eq                                                                   # [nT, d+1]
+    Pt = torch.cat([frow(touched[s0:s0 + 8192]) @ Eq for s0 in range(0, touched.numel(), 8192)])  # [nT, d+1]
     slot = torch.full((I,), -1, device=dev, dtype=torch.long); slot[touched] = torch.arange(touched.numel(), device=dev)
     Pi, Pj = Pt[slot[il]], Pt[slot[jl]]
     gu, tu = before["Gu"][ul], before["Tu"][ul]
@@ -54,6 +72,12 @@ def test_c2_full_size_step_against_torch_fp32():
     xn = before["Bi"][jl] + (gu * gj).sum(1) + (tu * Pj[:, :d]).sum(1) + Pj[:, d]
     got_xp = eng.score_pairs(u, i)
     torch.testing.assert_close(got_xp, xp, rtol=2e-4, atol=2e-4)
+    got_blk = eng.score_block(1000, 1064)                      # predict_all rows through the full-table projection
+    blk_want = before["Bi"][None, :] + before["Gu"][1000:1064] @ before["Gi"].T
+    Pall_d = torch.cat([frow(torch.arange(s0, min(I, s0 + 8192), device=dev)) @ Eq for s0 in range(0, I, 8192)])
+    blk_want = blk_want + before["Tu"][1000:1064] @ Pall_d[:, :d].T + Pall_d[:, d][None, :]
+    torch.testing.assert_close(got_blk, blk_want, rtol=2e-4, atol=2e-4)
+    del Pall_d, blk_want, got_blk
     diff = xp - xn
     gg = -torch.sigmoid(-diff)
     loss_want = torch.nn.functional.softplus(-diff).double().sum() + reg * (
@@ -74,9 +98,10 @@ def test_c2_full_size_step_against_torch_fp32():
         scatter(I, jl, (-gg + 0.2 * reg * before["Bi"][jl])[:, None])
     gth = torch.cat([gg[:, None] * tu, gg[:, None]], 1)
     W = (scatter(I, il, gth) - scatter(I, jl, gth)).float().to(torch.bfloat16).float()             # bf16 like the MFMA operand
+    del gth
     dEq = torch.zeros((D, d + 1), device=dev, dtype=torch.float32)
     for s0 in range(0, I, 8192):                                                                   # F^T W in fp32 chunks
-        dEq += F[s0:s0 + 8192].float().T @ W[s0:s0 + 8192]
+        dEq += frow(torch.arange(s0, min(I, s0 + 8192), device=dev)).T @ W[s0:s0 + 8192]
     want = {"Gu": before["Gu"] - lr * dGu.float(), "Tu": before["Tu"] - lr * dTu.float(),
             "Gi": before["Gi"] - lr * dGi.float(), "Bi": before["Bi"] - lr * dBi.float()[:, 0],
             "E": before["E"] - lr * (dEq[:, :d] + 2 * reg * before["E"]),
@@ -84,10 +109,14 @@ def test_c2_full_size_step_against_torch_fp32():
     for n, wv in want.items():
         delta_scale = float((wv - before[n]).abs().max()) + 1e-12
         err = float((eng.t[n] - wv).abs().max())
-        assert err <= 5e-3 * delta_scale + 1e-7, (n, err, delta_scale)      # error relative to the size of the update
+        assert err <= 5e-3 * delta_scale + 1e-7, (workload, n, err, delta_scale)      # error relative to the size of the update
     # conservation: with the +g / -g bias gradients, sum(dBi) carries only the regularisation terms
     assert abs(float(dBi.sum()) - float((2 * reg * before["Bi"][il].double()).sum()
                                          + (0.2 * reg * before["Bi"][jl].double()).sum())) < 1e-6 * B
+    # a second step from the updated state must keep every table finite and move the loss only slightly
+    loss2 = float(eng.step(u, i, j).item())
+    eng.sync_check()
+    assert np.isfinite(loss2) and abs(loss2 - loss) < 0.05 * abs(loss)
 
 
 def test_c3_shard_full_size_bprmf_against_torch_fp32():
