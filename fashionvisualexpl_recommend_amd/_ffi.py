@@ -17,7 +17,7 @@ MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
 FEAT_DTYPE = {"fp32": 0, "bf16": 1, "fp8": 2}
 E_RANGE = -4
-PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count", "cast_W_rows"]
+PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count"]
 
 
 class BprxError(RuntimeError):

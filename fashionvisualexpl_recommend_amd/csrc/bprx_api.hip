@@ -161,7 +161,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   if (const char *e = getenv("BPRX_LIST_MODE")) { const int v = atoi(e); h->list_policy = vb ? (v < 0 ? 0 : (v > 2 ? 2 : v)) : 0; }
   if (h->list_policy) {
     const size_t cap = 2 * MB < I ? 2 * MB : I;
-    if (dalloc_zero(&h->ilist, cap) != hipSuccess || dalloc_zero(&h->ilist_n, (size_t)1) != hipSuccess) {
+    if (dalloc_zero(&h->ilist, cap) != hipSuccess || dalloc_zero(&h->ilist_n, (size_t)2) != hipSuccess) {
       snprintf(g_create_err, sizeof(g_create_err), "item list allocation failed");
       free_scratch(h);
       delete h;
@@ -328,11 +328,12 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
   }
   if (h->list_mode) {
+    h->list_cur = h->ilist_n + h->list_slot;
+    h->list_bound = 2 * B < (int64_t)h->cfg.num_items ? 2 * B : (int64_t)h->cfg.num_items;
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;              // counts + the distinct-item list
-    const int64_t bound = 2 * B < (int64_t)h->cfg.num_items ? 2 * B : (int64_t)h->cfg.num_items;
     if (!h->p_valid &&                                                                   // P rows of the listed items only
-        (rc = bprx_launch_proj_fwd(h, h->ilist, bound, h->ilist_n, 1, h->P, s))) return rc;
+        (rc = bprx_launch_proj_fwd(h, h->ilist, h->list_bound, h->list_cur, 1, h->P, s))) return rc;
   } else if (vb && !h->proj_fresh) {
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if (!h->p_valid && (rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;  // every item
@@ -453,10 +454,11 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   // buffers, loss scalar, stream): it can be captured into a hipGraph once and replayed -- one launch per step.  Not for adam (lr_t changes every step), not while per-kernel profiling is
   // on, not on the legacy default stream (cannot be captured): those take the plain path.
   // Nor with fp8 features (the [E|Bp] absmax slot alternates on the host: a replayed graph would reuse one slot and never
-  // clear it), nor when a derived image is still valid at capture time (the captured sequence would lack its refresh).
+  // clear it).  The captured sequence is made self-contained: the derived images count as stale at capture time.
   const bool can_graph = h->graph_mode && h->cfg.optimizer == BPRX_OPT_SGD && !h->prof && stream != nullptr && !h->side &&
                          h->bound && B > 0 && B <= h->cfg.max_batch && user && pos && neg && !h->proj_fresh && !h->pending_B &&
-                         h->cfg.feat_dtype != BPRX_F_FP8 && !h->et_valid && !h->p_valid;
+                         h->cfg.feat_dtype != BPRX_F_FP8 &&
+                         (h->list_policy == 0 || (h->list_policy == 1 && 4 * B > (int64_t)h->cfg.num_items));   // list cursors alternate on the host
   if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
   hipStream_t s = (hipStream_t)stream;
   const bool same = h->graph_exec && h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg &&
@@ -472,6 +474,7 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
     h->graph_key.u = user; h->graph_key.i = pos; h->graph_key.j = neg; h->graph_key.loss = loss_out; h->graph_key.B = B;
     h->graph_key.stream = stream; h->graph_key.lr = h->cfg.lr; h->graph_key.reg = h->cfg.reg;
     if (!repeat) return step_plain(h, user, pos, neg, B, loss_out, stream);
+    h->et_valid = h->p_valid = false;                         // the graph refreshes Et and P itself on every replay
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
       (void)hipGetLastError();
       h->graph_mode = 0;                                      // this stream cannot be captured: plain launches from now on

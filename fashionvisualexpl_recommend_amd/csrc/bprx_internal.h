@@ -58,7 +58,11 @@ struct bprx_handle {
   int list_policy;                // 0 never, 1 per step (4B <= I), 2 always (env BPRX_LIST_MODE)
   int list_mode;                  // this step
   int32_t *ilist;                 // [min(2*max_batch, I)] distinct items of the batch, in arrival order (k_row_count)
-  int32_t *ilist_n;               // [1] their number; reset by k_dense_update (the last list consumer of a step has run)
+  int32_t *ilist_n;               // [2] their number, two cursors used by alternate list-mode steps: k_dense_update (the
+                                  //     last kernel of a step) clears the cursor the NEXT list-mode step appends through
+  int list_slot;                  // cursor of the next list-mode step
+  int32_t *list_cur;              // ilist_n + slot of the step in flight
+  int64_t list_bound;             // host-side bound of the list length of the step in flight: min(2B, I)
   bool list_reset_cnt;            // list mode: k_cast_W_rows resets cntI (no exclusive-row fast path on the item side)
   bool W_dirty;                   // the fp32 W table is not all-zero (left so by a dense fp32-feature step)
   int SK_step;                    // split-K slabs written by this step's backward projection (<= SK)

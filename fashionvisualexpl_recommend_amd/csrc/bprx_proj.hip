@@ -492,15 +492,17 @@ __device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t w, uint32_t &o0, uint32
 // F8: F holds fp8 codes (1 byte per element): the tile loads move half the bytes and the codes are widened to bf16 on
 // the way into LDS (W stays bf16); the slabs then hold (F*feat_scale)^T W and are rescaled where they are summed.
 // ROWS: the sum runs over the LISTED items only (sparse batches): tile row p is item rows[p], its feature pieces are
-// gathered from the tiled F (256 contiguous bytes per item and 128-column block), Wb is the COMPACT image (row p = list
-// position p), the list length comes from the device (*nrows_dev; `nrows` is the host-side bound) and the item splits are
-// cut from it here.
+// gathered from the tiled F (256 contiguous bytes per item and 128-column block) and its W row from the fp32 table Wf
+// (rows indexed by item id, as k_triplet_grad accumulated them; rounded to bf16 on the way into LDS -- no conversion
+// pass), the list length comes from the device (*nrows_dev; `nrows` is the host-side bound) and the item splits are cut
+// from it here.
 template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS = false>
 __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
                                                           const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
                                                           int rows_per_split, int descend, int xcd_map,
                                                           const int32_t *__restrict__ rows = nullptr,
-                                                          const int32_t *__restrict__ nrows_dev = nullptr) {
+                                                          const int32_t *__restrict__ nrows_dev = nullptr,
+                                                          const float *__restrict__ Wf = nullptr) {
   constexpr int NTH = NW * 64, MC = NW * 32;         // threads, feature columns per workgroup
   constexpr int ESZ = F8 ? 1 : 2;                    // bytes per feature element in HBM
   constexpr int FCH = MC * ESZ / 16;                 // 16-B pieces per F tile row (HBM side)
@@ -543,6 +545,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
   // PD tiles are in flight per workgroup (registers: PD * (FPT + WPT) * 4 VGPRs): the loop is latency-bound on the
   // global loads, so bytes in flight per CU set the delivered bandwidth
   uint4 freg[PD][FPT], wreg[PD][WPT];
+  uint4 wreg2[ROWS ? PD : 1][WPT];                   // ROWS: a 16-B bf16 piece of W is 32 B of the fp32 row
   // Loads are unconditional (rows / tiles past the end are clamped to the last valid one and zeroed at commit):
   // with a load inside a divergent branch the compiler waits for vmcnt(0) at every commit and the pipeline collapses.
 #define BWD3_ISSUE(ST, TILE)                                                                                             \
@@ -570,7 +573,13 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
       const int tr = idx / WCH, ch = idx % WCH;                                                                          \
       int t = t0 + tr;                                                                                                   \
       t = t < tend ? t : tend - 1;                                                                                       \
-      wreg[ST][x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);                                      \
+      if constexpr (ROWS) {                                                                                              \
+        const float *wr = Wf + (size_t)rows[t] * PS + ch * 8;                                                            \
+        wreg[ST][x] = *reinterpret_cast<const uint4 *>(wr);                                                              \
+        wreg2[ST][x] = *reinterpret_cast<const uint4 *>(wr + 4);                                                         \
+      } else {                                                                                                           \
+        wreg[ST][x] = *reinterpret_cast<const uint4 *>(Wb + (size_t)t * PS + ch * 8);                                    \
+      }                                                                                                                  \
     }                                                                                                                    \
   }
 #define BWD3_COMMIT(ST, TILE)                                                                                            \
@@ -597,6 +606,13 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
       const int idx = threadIdx.x + x * NTH, tr = idx / WCH, ch = idx % WCH;                                             \
       const uint32_t mk = (t0 + tr < tend) ? 0xffffffffu : 0u;                                                           \
       uint4 v = wreg[ST][x];                                                                                             \
+      if constexpr (ROWS) {                                                                                              \
+        const uint4 u = wreg2[ST][x];                                                                                    \
+        v.x = (uint32_t)f2bf(__uint_as_float(v.x)) | ((uint32_t)f2bf(__uint_as_float(v.y)) << 16);                       \
+        v.y = (uint32_t)f2bf(__uint_as_float(v.z)) | ((uint32_t)f2bf(__uint_as_float(v.w)) << 16);                       \
+        v.z = (uint32_t)f2bf(__uint_as_float(u.x)) | ((uint32_t)f2bf(__uint_as_float(u.y)) << 16);                       \
+        v.w = (uint32_t)f2bf(__uint_as_float(u.z)) | ((uint32_t)f2bf(__uint_as_float(u.w)) << 16);                       \
+      }                                                                                                                  \
       v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;                                                                        \
       if (idx < BTV * WCH) *reinterpret_cast<uint4 *>(&Ws[tr * WSB + ((tr & 8) << 4) + ch * 16]) = v;                    \
     }                                                                                                                    \
@@ -1144,32 +1160,6 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
   }
 }
 
-// List mode, after k_triplet_grad: the fp32 W rows of the listed items (accumulated by item id) become the COMPACT bf16
-// image the backward MFMA reads (row p = list position p; Wc == nullptr: fp32 features, W is read in place and this
-// kernel runs AFTER the backward projection), the W rows return to zero for the next step, and -- when nobody else does
-// it (no exclusive-row fast path) -- the row multiplicities are reset.  One float4 per thread.
-__global__ __launch_bounds__(256) void k_cast_W_rows(float *__restrict__ W, uint16_t *__restrict__ Wc, int PS,
-                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev,
-                                                     int bound, int32_t *__restrict__ cntI) {
-  const int per = PS / 4;
-  int n = *nrows_dev;
-  n = n < bound ? n : bound;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int p = (int)(e / per), c4 = (int)(e % per);
-  if (p >= n) return;
-  const int item = rows[p];
-  float4 *src = reinterpret_cast<float4 *>(W + (size_t)item * PS) + c4;
-  if (Wc) {
-    const float4 v = *src;
-    uint2 pk;
-    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-    reinterpret_cast<uint2 *>(Wc + (size_t)p * PS)[c4] = pk;
-  }
-  *src = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (cntI && c4 == 0) cntI[item] = 0;
-}
-
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
 
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
@@ -1337,7 +1327,7 @@ int launch_bwd_rows(bprx_handle *h, int64_t bound, hipStream_t s) {
 #define BWDR_LAUNCH(NW_, F8_)                                                                                            \
   hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32, NW_, 2, F8_, true>), g3, dim3(NW_ * 64), 0, s, (const uint16_t *)h->Ft,  \
                      (int)bound, D, (const uint16_t *)h->Wb, h->PS, h->part, 0, 0, 1, (const int32_t *)h->ilist,        \
-                     (const int32_t *)h->ilist_n)
+                     (const int32_t *)h->list_cur, (const float *)h->W)
   if (f8) BWDR_LAUNCH(8, true);
   else if (w8) BWDR_LAUNCH(8, false);
   else BWDR_LAUNCH(4, false);
@@ -1493,12 +1483,6 @@ int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s) {
       int sk = (int)((bound + 127) / 128);
       h->SK_step = sk < 1 ? 1 : (sk > h->SK ? h->SK : sk);
       {
-        BprxProfScope pc(h, BPRX_PHASE_CAST_W, s);
-        const int64_t n4 = bound * (h->PS / 4);
-        hipLaunchKernelGGL(k_cast_W_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, h->PS,
-                           (const int32_t *)h->ilist, (const int32_t *)h->ilist_n, (int)bound, h->list_reset_cnt ? h->cntI : nullptr);
-      }
-      {
         BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
 #define CALL(N) launch_bwd_rows<N>(h, bound, s)
         NT_SWITCH(NT, CALL)
@@ -1523,13 +1507,7 @@ int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s) {
       BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
       hipLaunchKernelGGL(k_proj_bwd_f32, dim3(D), dim3(256), 0, s, (const float *)h->t.F, h->list_mode ? (int)bound : I, D, h->W, d,
                          h->PS, h->dEp, h->list_mode ? (const int32_t *)h->ilist : (const int32_t *)nullptr,
-                         h->list_mode ? (const int32_t *)h->ilist_n : (const int32_t *)nullptr);
-    }
-    if (h->list_mode) {                                 // W rows back to zero (the dense form memsets W at the next step)
-      BprxProfScope pc(h, BPRX_PHASE_CAST_W, s);
-      const int64_t n4 = bound * (h->PS / 4);
-      hipLaunchKernelGGL(k_cast_W_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->W, (uint16_t *)nullptr, h->PS,
-                         (const int32_t *)h->ilist, (const int32_t *)h->ilist_n, (int)bound, h->list_reset_cnt ? h->cntI : nullptr);
+                         h->list_mode ? (const int32_t *)h->list_cur : (const int32_t *)nullptr);
     }
     BPRX_LAUNCH_CHECK(h, "k_proj_bwd_f32");
   }

@@ -62,6 +62,12 @@ __device__ __forceinline__ int clamp_idx(int v, int n, int32_t *errflag, int cod
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+__device__ __forceinline__ uint16_t f2bf_s(float x) {   // round-to-nearest-even; inputs are finite
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
 // x_ui = Bi[i] + <Gu[u],Gi[i]> (+ <Tu[u],P[0:d]> + P[d])
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void k_score(SparseArgs a, const int32_t *__restrict__ user,
@@ -510,48 +516,94 @@ __global__ void k_clear_flags(uint32_t *f, size_t n) {
 // Dense shared parameters E [D,d] and Bp [D]: grad = (sum of the SK split-K slabs of the backward projection, or the
 // all-reduced dEp) + 2*reg*param, then sgd or the dense ApplyAdam rule
 //   m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)                      (VBPR.py:142).
-// One thread per (k, n) of the padded [D][PS] slab layout (n <= d used).  ||E||^2+||Bp||^2 (pre-update, VBPR.py:127)
-// leaves as one double per block in sqpart[] (summed in fixed order by k_loss_reduce: no atomics, reproducible).
+// A block owns tiles of DU_KB k-rows x PS columns of the padded [D][PS] slab layout (contiguous: coalesced slab reads).
+// ||E||^2+||Bp||^2 (pre-update, VBPR.py:127) leaves as one double per block in sqpart[] (summed in fixed order by
+// k_loss_reduce: no atomics, reproducible).
+// The last kernel of a VBPR step also does the step's housekeeping, so that no separate launch has to:
+//   * bf16 features: the NEXT step's [E|Bp]^T images (chunk-major Et and fragment-major EtF, see k_cast_Et) are written
+//     from the updated values through an LDS transpose -- the step needs no k_cast_Et launch;
+//   * list mode: the fp32 W rows of the listed items return to zero, their multiplicities are reset when nobody else does
+//     it, and the OTHER list cursor (the one the next list-mode step appends through) is cleared.
+constexpr int DU_KB = 8;
 __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, float *__restrict__ Bp, float *mE, float *vE,
                                                       float *mBp, float *vBp, const float *__restrict__ dEp,
                                                       const float *__restrict__ part, int SK, int D, int d, int PS, int adam,
                                                       float lr_t, float reg, float b1, float b2, float eps,
-                                                      double *__restrict__ sqpart, float gscale, int32_t *__restrict__ ilist_n) {
+                                                      double *__restrict__ sqpart, float gscale, uint16_t *__restrict__ Et,
+                                                      uint16_t *__restrict__ EtF, const int32_t *__restrict__ ilist,
+                                                      const int32_t *__restrict__ ilist_n, int32_t *__restrict__ ilist_n_next,
+                                                      int bound, float *__restrict__ W, int32_t *__restrict__ cnt_reset) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[DU_KB][288];   // PS <= 272
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  if (ilist_n && blockIdx.x == 0 && threadIdx.x == 0) *ilist_n = 0;     // every consumer of this step's item list has run
+  if (ilist_n_next && blockIdx.x == 0 && threadIdx.x == 0) *ilist_n_next = 0;
+  if (ilist) {
+    int n = *ilist_n;
+    n = n < bound ? n : bound;
+    const int per = PS / 4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)n * per; e += (int64_t)gridDim.x * 256) {
+      const int p = (int)(e / per), c4 = (int)(e % per);
+      const int item = ilist[p];
+      reinterpret_cast<float4 *>(W + (size_t)item * PS)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cnt_reset && c4 == 0) cnt_reset[item] = 0;
+    }
+  }
   double sq = 0.0;
   const size_t total = (size_t)D * PS;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kk = (int)(e / PS), n = (int)(e % PS);
-    if (n > d) continue;
-    float gsum;
-    if (part) {                                        // fused split-K reduction (single-GPU step), fixed slab order
-      gsum = 0.f;
-      int sidx = 0;
-      for (; sidx + 8 <= SK; sidx += 8) {              // 8 independent loads in flight, then a fixed-order sum
-        float t[8];
+  const int ntile = (D + DU_KB - 1) / DU_KB;
+  for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+    const int k0 = tl * DU_KB;
+    for (int idx = threadIdx.x; idx < DU_KB * PS; idx += 256) {
+      const int kr = idx / PS, n = idx - kr * PS, kk = k0 + kr;
+      float nv = 0.f;
+      if (kk < D && n <= d) {
+        const size_t e = (size_t)kk * PS + n;
+        float gsum;
+        if (part) {                                      // fused split-K reduction (single-GPU step), fixed slab order
+          gsum = 0.f;
+          int sidx = 0;
+          for (; sidx + 8 <= SK; sidx += 8) {            // 8 independent loads in flight, then a fixed-order sum
+            float t[8];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) t[x] = part[(size_t)(sidx + x) * total + e];
+            for (int x = 0; x < 8; ++x) t[x] = part[(size_t)(sidx + x) * total + e];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) gsum += t[x];
+            for (int x = 0; x < 8; ++x) gsum += t[x];
+          }
+          for (; sidx < SK; ++sidx) gsum += part[(size_t)sidx * total + e];
+          gsum *= gscale;
+        } else {
+          gsum = n < d ? dEp[(size_t)kk * d + n] : dEp[(size_t)D * d + kk];
+        }
+        float *p = n < d ? E + (size_t)kk * d + n : Bp + kk;
+        const float pv = *p;
+        sq += (double)pv * (double)pv;
+        const float gg = gsum + 2.f * reg * pv;
+        if (adam) {
+          float *m = n < d ? mE + (size_t)kk * d + n : mBp + kk, *v = n < d ? vE + (size_t)kk * d + n : vBp + kk;
+          const float mt = *m + (gg - *m) * omb1;
+          const float vt = *v + (gg * gg - *v) * omb2;
+          *m = mt; *v = vt;
+          nv = pv - lr_t * mt / (sqrtf(vt) + eps);
+        } else {
+          nv = pv - lr_t * gg;
+        }
+        *p = nv;
       }
-      for (; sidx < SK; ++sidx) gsum += part[(size_t)sidx * total + e];
-      gsum *= gscale;
-    } else {
-      gsum = n < d ? dEp[(size_t)kk * d + n] : dEp[(size_t)D * d + kk];
+      if (Et) tile[kr][n] = f2bf_s(nv);
     }
-    float *p = n < d ? E + (size_t)kk * d + n : Bp + kk;
-    const float pv = *p;
-    sq += (double)pv * (double)pv;
-    const float gg = gsum + 2.f * reg * pv;
-    if (adam) {
-      float *m = n < d ? mE + (size_t)kk * d + n : mBp + kk, *v = n < d ? vE + (size_t)kk * d + n : vBp + kk;
-      const float mt = *m + (gg - *m) * omb1;
-      const float vt = *v + (gg * gg - *v) * omb2;
-      *m = mt; *v = vt;
-      *p = pv - lr_t * mt / (sqrtf(vt) + eps);
-    } else {
-      *p = pv - lr_t * gg;
+    if (Et) {                                            // D % 128 == 0 with bf16 features: whole tiles only
+      __syncthreads();
+      for (int n = threadIdx.x; n < PS; n += 256) {
+        uint4 v;
+        v.x = (uint32_t)tile[0][n] | ((uint32_t)tile[1][n] << 16);
+        v.y = (uint32_t)tile[2][n] | ((uint32_t)tile[3][n] << 16);
+        v.z = (uint32_t)tile[4][n] | ((uint32_t)tile[5][n] << 16);
+        v.w = (uint32_t)tile[6][n] | ((uint32_t)tile[7][n] << 16);
+        const int e = k0 & 127;                          // k0 % 8 == 0: both images take the 8 values as one 16-B piece
+        *reinterpret_cast<uint4 *>(Et + ((size_t)(k0 >> 7) * PS + n) * 128 + e) = v;
+        *reinterpret_cast<uint4 *>(EtF + (((((size_t)(k0 >> 7) * 4 + (e >> 5)) * (PS >> 4) + (n >> 4)) * 64) +
+                                          ((e >> 3) & 3) * 16 + (n & 15)) * 8) = v;
+      }
+      __syncthreads();
     }
   }
   __shared__ double red[256];
@@ -601,11 +653,6 @@ __global__ __launch_bounds__(256) void k_score_block(SparseArgs a, int u0, int u
 }
 
 
-__device__ __forceinline__ uint16_t f2bf_s(float x) {   // round-to-nearest-even; inputs are finite
-  uint32_t u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // Item-side gradients without global float atomics ("occurrence segments").
@@ -959,7 +1006,7 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
                        a.fastU, (a.fastI || h->list_mode) ? 1 : 0, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
                        h->item_mode ? h->seg_cursor : (int32_t *)nullptr, (uint4 *)(zw ? h->Wb : nullptr),
                        zw ? (size_t)a.I * a.PS * sizeof(uint16_t) / 16 : (size_t)0,
-                       h->list_mode ? h->ilist : (int32_t *)nullptr, h->ilist_n, (int)cap);
+                       h->list_mode ? h->ilist : (int32_t *)nullptr, h->list_cur, (int)cap);
   }
   if (h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
@@ -1052,8 +1099,8 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
 }
 
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
-  const size_t total = (size_t)h->cfg.feat_dim * h->PS;
-  unsigned blocks = (unsigned)((total + 255) / 256);
+  const int D = h->cfg.feat_dim;
+  unsigned blocks = (unsigned)((D + DU_KB - 1) / DU_KB);
   if (blocks > BPRX_DENSE_BLOCKS) blocks = BPRX_DENSE_BLOCKS;
   h->dense_blocks = (int)blocks;
   BprxProfScope ps(h, BPRX_PHASE_DENSE, s);
@@ -1061,13 +1108,21 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   const float *part = (h->fused_reduce && h->cfg.feat_dtype != BPRX_F_FP32) ? h->part : nullptr;
   // fp8 features: the slabs hold (F*feat_scale)^T W; an all-reduced dEp was already rescaled by k_reduce_parts
   const float gscale = (part && h->cfg.feat_dtype == BPRX_F_FP8) ? 1.0f / h->cfg.feat_scale : 1.0f;
+  // bf16 features: this kernel writes the next step's [E|Bp]^T images (fp8 images need the global max first: k_cast_Et8)
+  const bool images = h->cfg.feat_dtype == BPRX_F_BF16 && !getenv("BPRX_NO_ET_FUSE");
+  const bool lm = h->list_mode != 0;
+  const int64_t bound = lm ? h->list_bound : 0;
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
-                     h->t.v_Bp, h->dEp, part, h->SK_step, h->cfg.feat_dim, h->cfg.embed_d, h->PS,
+                     h->t.v_Bp, h->dEp, part, h->SK_step, D, h->cfg.embed_d, h->PS,
                      h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg, h->cfg.beta1, h->cfg.beta2,
-                     h->cfg.epsilon, h->loss_acc, gscale, h->ilist_n);
-  h->et_valid = false;                                  // E / Bp move: the bf16 / fp8 image and the projections are stale
-  h->p_valid = false;
+                     h->cfg.epsilon, h->loss_acc, gscale, images ? (uint16_t *)h->Et : (uint16_t *)nullptr, (uint16_t *)h->EtF,
+                     lm ? (const int32_t *)h->ilist : (const int32_t *)nullptr, (const int32_t *)h->list_cur,
+                     lm ? h->ilist_n + (h->list_slot ^ 1) : (int32_t *)nullptr, (int)bound, h->W,
+                     (lm && h->list_reset_cnt) ? h->cntI : (int32_t *)nullptr);
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
+  if (lm) { h->list_slot ^= 1; h->list_mode = 0; }      // the step's list is consumed
+  h->et_valid = images;                                 // E / Bp moved: the images were refreshed here, or are stale
+  h->p_valid = false;                                   //               the item projections are stale
   return BPRX_OK;
 }
 

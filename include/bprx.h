@@ -176,7 +176,7 @@ BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out
 enum {
   BPRX_PHASE_CAST_ET = 0, BPRX_PHASE_PROJ_FWD = 1, BPRX_PHASE_TRIPLET = 2, BPRX_PHASE_PROJ_BWD = 3,
   BPRX_PHASE_REDUCE = 4, BPRX_PHASE_APPLY = 5, BPRX_PHASE_DENSE = 6, BPRX_PHASE_LOSS = 7, BPRX_PHASE_ITEM_SEG = 8,
-  BPRX_PHASE_SEG_ALLOC = 9, BPRX_PHASE_ROW_COUNT = 10, BPRX_PHASE_CAST_W = 11, BPRX_PHASE_COUNT = 12
+  BPRX_PHASE_SEG_ALLOC = 9, BPRX_PHASE_ROW_COUNT = 10, BPRX_PHASE_COUNT = 11
 };
 BPRX_API int bprx_profile_enable(bprx_handle *h, int on);
 BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);
