@@ -43,7 +43,10 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps between barrier + synchronize) is run this many times; "
+                         "value / ms_per_step are the MEDIAN repeat, every repeat is listed in repeats_ms")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
@@ -63,6 +66,8 @@ def parse():
                     help="draw each batch one step ahead on a side stream (measured on C2: 0.287 vs 0.280 ms/step without "
                          "-- the sampler then competes with the step's kernels; off by default)")
     ap.add_argument("--cpu-sample-steps", type=int, default=60)
+    ap.add_argument("--cpu-eager-seconds", type=float, default=10.0,
+                    help="wall-clock budget of the like-for-like eager CPU baseline (BASELINE.md B1); 0 = skip")
     return ap.parse_args()
 
 
@@ -266,21 +271,32 @@ def main():
     # legacy default stream cannot be captured -- measured slower than plain launches, so it is off by default)
     run_stream = torch.cuda.Stream(device=device)
     run_stream.wait_stream(torch.cuda.current_stream())
+    repeats = []
     with torch.cuda.stream(run_stream):
         for s in range(W):
             one_step(s)
-        barrier()
-        t0 = time.perf_counter()
-        for s in range(K):
-            one_step(W + s)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        for rep in range(max(1, args.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for s in range(K):                                # EXACTLY K steps between barrier + synchronize
+                one_step(W + rep * K + s)
+            barrier()
+            repeats.append(time.perf_counter() - t0)
     torch.cuda.current_stream().wait_stream(run_stream)
     if world > 1:
-        tmax = torch.tensor([elapsed], device="cpu" if rehearse else device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tmax = torch.tensor(repeats, device="cpu" if rehearse else device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)           # MAX over ranks, per repeat
+        repeats = [float(x) for x in tmax.tolist()]
+    elapsed = float(np.median(repeats))                       # the median repeat is the reported one
     eng.sync_check()
+
+    # what this device's HBM delivers to a plain streaming-read kernel (bprx_probe_stream_read), on the launch stream
+    measured_peak = None
+    if rank == 0:
+        try:
+            measured_peak = hbm_stream_probe(torch, device, run_stream)
+        except Exception as e:                                # never let the probe take the bench line down
+            print("hbm probe failed: %r" % (e,), file=sys.stderr)
 
     # per-kernel durations: a second pass over the same K steps with HIP events around every kernel launch
     eng.profile(True)
@@ -308,15 +324,19 @@ def main():
                 "triplet_grad": B * (24 * w["k"] + 28 + 8 * w["d"] + 2 * PS * 4 + 2 * PS * 4) / 1.0,
                 "apply": 3 * B * 0 + B * (12 * (w["k"] + w["d"]) + 24 * w["k"]),
             }
+            if 4 * B <= w["I"]:      # touched-item list mode: the projections move the batch's distinct rows (count known on
+                kern_bytes.pop("proj_fwd"), kern_bytes.pop("proj_bwd")     # the device only): no algorithmic figure quoted
         else:
             kern_bytes = {"triplet_grad": B * (24 * w["k"] + 28), "apply": B * 36 * w["k"]}
         # HBM bytes per launch from PMC counters, measured offline with scripts/pmc.sh on this same workload and
         # committed under profiles/ (bench.py itself cannot run under rocprofv3 --pmc); null when not available
-        traffic = None
+        traffic, pmc, pmc_ok = None, {}, False
+        list_mode_run = w["model"] == "vbpr" and 4 * B <= w["I"]      # libbprx's per-step policy (touched-item list)
         try:
-            pt = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-            if args.workload == "c2" and B == WORKLOADS["c2"]["B"] and dom in pt:
-                traffic = pt[dom]["hbm_bytes"]
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
+            pmc_ok = args.workload == "c2" and B == WORKLOADS["c2"]["B"] and args.optimizer == "sgd"
+            if pmc_ok and dom in pmc:
+                traffic = pmc[dom]["hbm_bytes"]
         except Exception:
             traffic = None
         rl = None
@@ -324,10 +344,27 @@ def main():
             ach = kern_bytes[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
             rl = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": kern_bytes[dom],
-                  "avg_ms": kernels[dom]["avg_ms"]}
+                  "avg_ms": kernels[dom]["avg_ms"],
+                  # the same achieved rate against what a plain streaming-read kernel reaches on THIS device, measured
+                  # in this run (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+                  "measured_peak": measured_peak, "frac_of_measured": (ach / measured_peak) if measured_peak else None}
+            # MFMA utilisation of the two projections (north_star: "MFMA utilisation on the projection against gfx950
+            # peak"): flops EXECUTED per launch (2*I*D*PS each, padded columns included) / HIP-event duration / dense peak
+            # (2.5 PF bf16; fp8 features: the forward uses the fp8 MFMA -> 5 PF, the backward widens F to bf16 -> 2.5 PF);
+            # busy_pmc = SQ_VALU_MFMA_BUSY_CYCLES share measured offline by scripts/pmc.sh (profiles/), when available
+            if w["model"] == "vbpr" and w["dtype"] != "fp32" and not list_mode_run:
+                fl = 2.0 * w["I"] * w["D"] * PS
+                mu = {}
+                for ph, peak in (("proj_fwd", 5000.0 if w["dtype"] == "fp8" else 2500.0), ("proj_bwd", 2500.0)):
+                    if ph in kernels:
+                        tf = fl / (kernels[ph]["avg_ms"] * 1e-3) / 1e12
+                        mu[ph] = {"flops_per_launch": fl, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                  "busy_pmc": (pmc.get(ph, {}) or {}).get("mfma_busy_frac") if pmc_ok else None}
+                rl["mfma_util"] = mu
         out = {
             "metric": "BPR triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "repeats_ms": [r / K * 1e3 for r in repeats],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": w["dtype"] if w["model"] == "vbpr" else "fp32", "data": "synthetic",
             "config": {"workload": "%s: %s k=%d d=%d D=%d, %d users x %d items per GPU, %s features, B=%d per GPU, %s"
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
@@ -350,9 +387,95 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, tables, args.cpu_sample_steps, args.optimizer)
+            if args.cpu_eager_seconds > 0:
+                out["cpu_baseline_eager"] = cpu_baseline_eager(w, tables, args.cpu_eager_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_stream_probe(torch, device, stream):
+    """GB/s of bprx_probe_stream_read over a 1-GiB buffer (far larger than the 256-MiB Infinity Cache), best of 5 timed
+    launches after 2 warm-ups, timed with events on the launch stream."""
+    import ctypes as C
+    from fashionvisualexpl_recommend_amd import _ffi
+    L = _ffi.lib()
+    nbytes = 1 << 30
+    buf = torch.ones(nbytes // 4, dtype=torch.float32, device=device)
+    sink = torch.zeros(4096, dtype=torch.float32, device=device)
+    best = 0.0
+    with torch.cuda.stream(stream):
+        sp = C.c_void_p(stream.cuda_stream)
+        for it in range(7):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            got = L.bprx_probe_stream_read(C.c_void_p(buf.data_ptr()), nbytes, C.c_void_p(sink.data_ptr()), sp)
+            b.record(stream)
+            b.synchronize()
+            if got < 0:
+                raise RuntimeError("bprx_probe_stream_read failed: %d" % got)
+            if it >= 2:
+                best = max(best, got / (a.elapsed_time(b) * 1e-3) / 1e9)
+    del buf, sink
+    return best
+
+
+def cpu_baseline_eager(w, tables, seconds):
+    """the reference's train_step restated op-for-op in torch CPU EAGER mode (gather -> mul/reduce or matmul
+    -> softplus -> autograd -> optimizer), batch 256 like the reference's default (train_rec.py:23), full-size fp32 tables on
+    the host, Adam over dense gradients (every row of every table moves every step, like TF-2.3's non-lazy sparse apply:
+    BPRMF.py:52,123 / VBPR.py:56,142), default intra-op threads.  Mirrors the STRUCTURE of the reference's eager TF loop
+    (one kernel per op, a host sync per step for the loss, BPRMF.py:125); it is a timing baseline, not a parity check."""
+    import torch
+    B = 256
+    vb = w["model"] == "vbpr"
+    host = lambda n: tables[n].detach().float().cpu()
+    params = {n: torch.nn.Parameter(host(n)) for n in (("Gu", "Gi", "Bi", "Tu", "E", "Bp") if vb else ("Gu", "Gi", "Bi"))}
+    F = None
+    if vb:
+        F = host("F")
+        if w["dtype"] == "fp8":
+            F /= 448.0
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3, eps=1e-7)
+    g = torch.Generator().manual_seed(11)
+    reg = 1e-4
+
+    def call(u, i):                                             # BPRMF.py:55-76 / VBPR.py:59-86
+        gu, gi, bi = params["Gu"].index_select(0, u), params["Gi"].index_select(0, i), params["Bi"].index_select(0, i)
+        x = bi + (gu * gi).sum(1)
+        tu = None
+        if vb:
+            tu, fi = params["Tu"].index_select(0, u), F.index_select(0, i)
+            x = x + (tu * (fi @ params["E"])).sum(1) + fi @ params["Bp"]
+        return x, bi, gu, gi, tu
+
+    def step():
+        u = torch.randint(w["U"], (B,), generator=g)
+        i = torch.randint(w["I"], (B,), generator=g)
+        j = torch.randint(w["I"], (B,), generator=g)
+        xp, bi, gu, gi, tu = call(u, i)
+        xn, bj, _, gj, _ = call(u, j)
+        loss = torch.nn.functional.softplus(-torch.clamp(xp - xn, -80.0, 1e8)).sum()
+        loss = loss + reg * ((gu ** 2).sum() + (gi ** 2).sum() + (gj ** 2).sum()) + reg * (bi ** 2).sum() + reg / 10 * (bj ** 2).sum()
+        if vb:
+            loss = loss + reg * (tu ** 2).sum() + reg * ((params["E"] ** 2).sum() + (params["Bp"] ** 2).sum())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(loss)                                      # loss.numpy(): the reference's per-step host sync
+
+    step()                                                      # warm-up (allocations, Adam slots)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 >= seconds and n >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * B / dt, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "eager",
+            "sample": "%d steps of B=%d (the reference's default batch) in %.1f s on the FULL %d x %d tables, fp32, torch-CPU "
+                      "eager + autograd + Adam(dense grads, eps=1e-7), intra-op threads = %d"
+                      % (n, B, dt, w["U"], w["I"], torch.get_num_threads())}
 
 
 def cpu_baseline(w, tables, steps, optimizer):
@@ -379,8 +502,9 @@ def cpu_baseline(w, tables, steps, optimizer):
         o.step(rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B), optimizer, 1e-4, 1e-4)
     dt = time.perf_counter() - t0
     return {"value": steps * B / dt, "unit": "triplets/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of B=%d triplets on a 1/%d slice (%d users x %d items) of the same tables, same k/d/D"
-                      % (steps, B, f, U, I)}
+            "sample": "%d steps of B=%d triplets on a 1/%d slice (%d users x %d items) of the same tables, same k/d/D; the "
+                      "oracle's projections and F^T W are OpenMP-parallel over %d threads, its per-triplet loop is serial"
+                      % (steps, B, f, U, I, cores)}
 
 
 if __name__ == "__main__":

@@ -198,6 +198,11 @@ BPRX_API int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const float
    instantiation against the plain kernel. */
 BPRX_API int bprx_kernel_variant_safe(int ver, int nt, int mt, int rem);
 
+/* Measurement helper (bench.py): one launch of a plain streaming-read kernel over buf[0, bytes) (device memory, >= 64 MiB;
+   sink: >= 8 KiB of device scratch).  Returns the number of bytes the launch reads, or a negative BPRX_E_* code.  Timed by
+   the caller on `stream`: the rate this device's HBM delivers to a streaming kernel, quoted beside the 8 TB/s spec. */
+BPRX_API int64_t bprx_probe_stream_read(const void *buf, int64_t bytes, void *sink, void *stream);
+
 /* Synchronise `stream` and report deferred device-side errors (index out of range). */
 BPRX_API int bprx_sync_check(bprx_handle *h, void *stream);
 
