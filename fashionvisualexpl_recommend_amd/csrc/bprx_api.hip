@@ -26,7 +26,7 @@ static void graph_drop(bprx_handle *h) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -97,7 +97,9 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       h->SK = (ncu + mr - 1) / mr;
       // fp8 tiles are half the bytes, wide projections (more than 9 column tiles) have no registers for a third tile in
       // flight: both keep two workgroups per CU with two tiles in flight (measured: c2fp8 53 vs 58 us, c5 124 vs 362 us)
-      if (cfg->feat_dtype == BPRX_F_FP8 || PS / 16 > 9) h->SK *= 2;
+      // (wide projections, re-measured with the 8-wave kernel at two tiles in flight -- c5: SK 16 / 24 / 32 = 120 / 154 / 127 us
+      //  backward and 24 / 30 / 38 us dense update: one workgroup per CU there as well)
+      if (cfg->feat_dtype == BPRX_F_FP8 && PS / 16 <= 9) h->SK *= 2;
     }
     if (h->SK > 64) h->SK = 64;
     if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
@@ -116,6 +118,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     A(dalloc_zero(&h->Ppair, MB * PS));
     A(dalloc_zero((uint16_t **)&h->Et, PS * D));
     A(dalloc_zero((uint16_t **)&h->EtF, PS * D));
+    if (cfg->feat_dtype == BPRX_F_FP8 && PS / 16 >= 10) A(dalloc_zero((uint8_t **)&h->EtS, PS * D));
     A(dalloc_zero(&h->dEp, D * d + D));
     A(dalloc_zero(&h->part, (size_t)h->SK * D * PS));
     A(dalloc_zero(&h->qs, (size_t)4));
@@ -252,7 +255,7 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
   if (((uintptr_t)t->Gu | (uintptr_t)t->Gi | (uintptr_t)t->Tu | (uintptr_t)t->F | (uintptr_t)t->E) & 15)
     BPRX_FAIL(h, BPRX_E_INVALID, "bind_tables: table base pointers must be 16-byte aligned");
   h->t = *t;
-  h->et_valid = h->p_valid = false;
+  h->et_valid = h->p_valid = h->absmax_valid = false;
   graph_drop(h);                            // a captured step holds the old table pointers
   {
     const int rc = bprx_launch_tile_F(h);   // the projections read a tiled copy of the frozen F (made here, once)
@@ -264,7 +267,7 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
 
 extern "C" int bprx_tables_dirty(bprx_handle *h) {
   if (!h) return BPRX_E_INVALID;
-  h->et_valid = h->p_valid = false;
+  h->et_valid = h->p_valid = h->absmax_valid = false;
   return BPRX_OK;
 }
 

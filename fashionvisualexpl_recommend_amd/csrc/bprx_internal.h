@@ -38,12 +38,14 @@ struct bprx_handle {
   void *Ft;                       // tiled copy of F (bf16 / fp8 features): 8-KB blocks of 32 items x 256 B, see k_tile_F
   void *Et;                       // bf16 [PS][D]: [E|Bp|0]^T, refreshed every step
   void *EtF;                      // the same values in MFMA-fragment-major order (k_proj_fwd_rows), see k_cast_Et
+  void *EtS;                      // fp8 features, PS/16 >= 10: the codes in the order of k_proj_fwd_f8s (scaled fp8 MFMA)
   float *dEp;                     // [D*d + D] dense gradient of E then Bp (no regularisation term)
   float *part;                    // [SK][D][PS] split-K slabs of the backward projection
   int SK;
   float *qs;                      // fp8 features: [1] = 1/(feat_scale*sE) for P, [2], [3] = max|E,Bp| bits (uint32, atomicMax;
                                   //               two slots used alternately, the idle one is cleared by k_cast_Et8)
   int qs_slot;
+  bool absmax_valid;              // fp8: qs[2 + qs_slot] already holds max|E,Bp| of the bound values (left by k_dense_update)
   int fast_rows;                  // sgd: rows used by exactly one triplet of the batch are updated in place
   int32_t *cntU, *cntI;           // [U], [I] row multiplicities of the current batch (all-zero between steps)
   int seg_policy;                 // 0 never, 1 per step (2B >= I), 2 always (env BPRX_ITEM_MODE)

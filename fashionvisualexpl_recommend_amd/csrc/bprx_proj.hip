@@ -70,33 +70,37 @@ __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ E, siz
   }
 }
 
-// fp8 image of [E|Bp|0]^T: e4m3fn(x * sE), sE = 448 / max|E,Bp|, chunk-major with 256-wide chunks (256-byte rows: the
-// same BYTE layout as the bf16 image with 128-wide chunks, so the forward kernels are shared).  Block (0,0) also
-// publishes qs[1] = 1 / (feat_scale * sE), the factor that turns the fp8 products back into P.
+// fp8 images of [E|Bp|0]^T: e4m3fn(x * sE), sE = 448 / max|E,Bp|.  One block per 16 k-rows: the codes of a (column n,
+// 16 consecutive k) run are one 16-byte piece in each of the three images, written with one store each:
+//   Et   chunk-major with 256-wide chunks (256-byte rows: the same BYTE layout as the bf16 image with 128-wide chunks, so
+//        the forward kernels are shared):      ((k/256)*PS + n)*256 + k%256
+//   EtF  fragment-major for k_proj_fwd_rows:   ((((k/256)*4 + (k%256)/64) * PS/16 + n/16) * 64 + ((k%64)/16)*16 + n%16) * 16
+//   EtS  (optional, wide projections) the order of k_proj_fwd_f8s:
+//                                              ((((k/128) * PS/16 + n/16) * 2 + (k%32)/16) * 64 + ((k%128)/32)*16 + n%16) * 16
+// Block 0 also publishes qs[1] = 1 / (feat_scale * sE), the factor that turns the fp8 products back into P, and clears
+// the absmax slot of the NEXT cast.
 __global__ __launch_bounds__(256) void k_cast_Et8(const float *__restrict__ E, const float *__restrict__ Bp,
-                                                  uint8_t *__restrict__ Et, uint8_t *__restrict__ EtF, int D, int d, int PS,
-                                                  float *__restrict__ qs, float feat_scale, int slot) {
-  __shared__ float tile[64][17];
-  const float amax = qs[2 + slot];                         // written by k_absmax just before; the other slot is cleared here
-  const float sE = amax > 0.f ? 448.0f / amax : 1.0f;      // for the next step's k_absmax (no memset launch per step)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { qs[1] = 1.0f / (feat_scale * sE); qs[2 + (slot ^ 1)] = 0.f; }
-  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
-  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
-    const int kr = idx >> 4, nc = idx & 15, kk = k0 + kr, n = n0 + nc;
+                                                  uint8_t *__restrict__ Et, uint8_t *__restrict__ EtF, uint8_t *__restrict__ EtS,
+                                                  int D, int d, int PS, float *__restrict__ qs, float feat_scale, int slot) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[288][16];        // [n][k within the 16-row group]
+  const float amax = qs[2 + slot];                         // k_absmax / k_dense_update; the other slot is cleared here for
+  const float sE = amax > 0.f ? 448.0f / amax : 1.0f;      // the next round (no memset launch per step)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { qs[1] = 1.0f / (feat_scale * sE); qs[2 + (slot ^ 1)] = 0.f; }
+  const int k0 = blockIdx.x * 16, NT = PS >> 4;
+  for (int idx = threadIdx.x; idx < 16 * PS; idx += 256) {
+    const int kr = idx / PS, n = idx - kr * PS, kk = k0 + kr;
     float v = 0.f;
     if (kk < D) v = n < d ? E[(size_t)kk * d + n] : (n == d ? Bp[kk] : 0.f);
-    tile[kr][nc] = v;
+    tile[n][kr] = (uint8_t)f2e4m3(v * sE);
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
-    const int nc = idx >> 6, kr = idx & 63, kk = k0 + kr, n = n0 + nc;
-    if (n < PS && kk < D) {
-      const uint8_t code = (uint8_t)f2e4m3(tile[kr][nc] * sE);
-      Et[((size_t)(kk >> 8) * PS + n) * 256 + (kk & 255)] = code;
-      // fragment-major twin (k_proj_fwd_rows): byte b = kk & 255 of chunk kk >> 8 -> k-step b >> 6, lane quarter (b >> 4) & 3
-      const int b = kk & 255;
-      EtF[(((((size_t)(kk >> 8) * 4 + (b >> 6)) * (PS >> 4) + (n >> 4)) * 64) + ((b >> 4) & 3) * 16 + (n & 15)) * 16 + (b & 15)] = code;
-    }
+  for (int n = threadIdx.x; n < PS; n += 256) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(&tile[n][0]);
+    const int b = k0 & 255, bs = k0 & 127;
+    *reinterpret_cast<uint4 *>(Et + ((size_t)(k0 >> 8) * PS + n) * 256 + b) = v;
+    *reinterpret_cast<uint4 *>(EtF + (((((size_t)(k0 >> 8) * 4 + (b >> 6)) * NT + (n >> 4)) * 64) + ((b >> 4) & 3) * 16 + (n & 15)) * 16) = v;
+    if (EtS)
+      *reinterpret_cast<uint4 *>(EtS + (((((size_t)(k0 >> 7) * NT + (n >> 4)) * 2 + ((bs >> 4) & 1)) * 64) + (bs >> 5) * 16 + (n & 15)) * 16) = v;
   }
 }
 
@@ -1100,6 +1104,151 @@ __global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__r
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// forward, fp8 features, WIDE projections (NT >= 10 column tiles: BASELINE.json configs[4], k = d = 256 -> PS = 272) in ONE
+// pass over F on the block-scaled fp8 MFMA.  The v8 kernel keeps two waves per SIMD (256 registers each) and therefore
+// covers at most nine column tiles per launch: d = 256 took three column-range launches, i.e. three reads of F, on the
+// non-scaled fp8 MFMA that runs at the bf16 rate.  Here:
+//   * an 8-wave workgroup per CU, a wave owns up to two 16-row tiles and ALL NT column tiles -- 2*NT*4 accumulator
+//     registers (136 at NT = 17), which with one-step-ahead fragment reads fits the 256-register budget of two waves per
+//     SIMD -- so F is read exactly once.  (One wave per SIMD with four tiles, 272 accumulators in the 512-register file,
+//     was tried first: hipcc keeps MFMA accumulators in AGPRs only, spilled the 16 beyond 256 and renamed them with
+//     hundreds of v_accvgpr moves per chunk.)
+//   * v_mfma_scale_f32_16x16x128_f8f6f4 with unit (E8M0 = 127) scales: K = 128 per instruction at twice the bf16 rate
+//     per clock (MI355X_MICROARCH.md, Matrix cores).  Operands are 32 B per lane: lane (i = l & 15, g = l >> 4) holds
+//     k = 32 g .. 32 g + 31 of row / column i; A and B use the same k split, so any k order inside it is consistent;
+//   * the [E|Bp]^T chunk (NT*2 KB per 128 k) is staged through LDS, shared by the four waves, from the image EtS that
+//     k_cast_Et8 writes in exactly the LDS order ((chunk, column tile, half, lane) x 16 B): the global -> LDS copy is a
+//     straight contiguous copy and every fragment read is a conflict-free 1-KB ds_read_b128;
+//   * two-stage pipeline, one barrier per chunk: chunk c+1's feature fragments and B pieces are requested before chunk
+//     c's MFMAs (scheduling fences keep hipcc from sinking them), the B pieces are parked in the other LDS buffer after.
+// Balanced share of the row tiles per workgroup as in v8; the body is instantiated for 1 and 2 row tiles and picked per wave.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+template <int NT, int MT>
+__device__ __forceinline__ void f8s_body(const unsigned char *const (&arow)[2], const unsigned char *__restrict__ EtS,
+                                         unsigned char *lds, int nch, int cshift, int lane, float *__restrict__ P, int PS,
+                                         int nrows, int first, int nstore, float ps) {
+  constexpr int BCH = NT * 2048;                        // bytes of one [E|Bp]^T chunk
+  constexpr int NPIECE = NT * 128;                      // its 16-B pieces
+  constexpr int NBP = (NPIECE + 511) / 512;             // pieces per thread (the last round clamps onto the last piece)
+  const int tid = threadIdx.x;
+  // accumulators live and die inside this instantiation (no merge of the instantiations' accumulators after the switch)
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x8_t aX[MT], aY[MT];                               // 32 B per lane and row tile: one scaled-MFMA A operand
+  i32x4_t bst[NBP];
+#define F8S_ISSUE(c_, AR)                                                                                             \
+  {                                                                                                                   \
+    int ce_ = (c_) + cshift;                                                                                          \
+    if (ce_ >= nch) ce_ -= nch;                                                                                       \
+    const size_t ao_ = (size_t)(ce_ >> 1) * 8192 + (size_t)(ce_ & 1) * 128;                                           \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                               \
+      AR[mt].lo = *reinterpret_cast<const i32x4_t *>(arow[mt] + ao_);                                                 \
+      AR[mt].hi = *reinterpret_cast<const i32x4_t *>(arow[mt] + ao_ + 16);                                            \
+    }                                                                                                                 \
+    const unsigned char *bc_ = EtS + (size_t)ce_ * BCH;                                                               \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                 \
+      int pc = tid + x * 512;                                                                                         \
+      pc = pc < NPIECE ? pc : NPIECE - 1;                                                                             \
+      bst[x] = *reinterpret_cast<const i32x4_t *>(bc_ + pc * 16);                                                     \
+    }                                                                                                                 \
+  }
+#define F8S_PARK(buf_)                                                                                                \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                 \
+      int pc = tid + x * 512;                                                                                         \
+      pc = pc < NPIECE ? pc : NPIECE - 1;                                                                             \
+      *reinterpret_cast<i32x4_t *>(lds + (buf_) * BCH + pc * 16) = bst[x];                                            \
+    }                                                                                                                 \
+  }
+#define F8S_COMPUTE(buf_, AR)                                                                                         \
+  {                                                                                                                   \
+    /* fragment nt+1 is read from LDS before the MFMAs of fragment nt; the fences keep hipcc from hoisting ALL NT     \
+       fragment reads (8 registers each) above the first MFMA */                                                      \
+    const unsigned char *bl_ = lds + (buf_) * BCH + lane * 16;                                                        \
+    i32x8_t bq[2];                                                                                                    \
+    bq[0].lo = *reinterpret_cast<const i32x4_t *>(bl_);                                                               \
+    bq[0].hi = *reinterpret_cast<const i32x4_t *>(bl_ + 1024);                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                               \
+      if (nt + 1 < NT) {                                                                                              \
+        bq[(nt + 1) & 1].lo = *reinterpret_cast<const i32x4_t *>(bl_ + (nt + 1) * 2048);                              \
+        bq[(nt + 1) & 1].hi = *reinterpret_cast<const i32x4_t *>(bl_ + (nt + 1) * 2048 + 1024);                       \
+      }                                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                               \
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(AR[mt], bq[nt & 1], acc[mt][nt], 0, 0, 0,      \
+                                                                       0x7f7f7f7f, 0, 0x7f7f7f7f);                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }                                                                                                                 \
+  }
+  F8S_ISSUE(0, aX)
+  F8S_PARK(0)
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {                    // nch is even (D % 256 == 0); the last prefetch re-reads chunk nch-1
+    F8S_ISSUE(c + 1, aY)
+    __builtin_amdgcn_sched_barrier(0);
+    F8S_COMPUTE(0, aX)
+    F8S_PARK(1)
+    __syncthreads();
+    const int cn = c + 2 < nch ? c + 2 : nch - 1;
+    F8S_ISSUE(cn, aX)
+    __builtin_amdgcn_sched_barrier(0);
+    F8S_COMPUTE(1, aY)
+    F8S_PARK(0)
+    __syncthreads();
+  }
+#undef F8S_ISSUE
+#undef F8S_PARK
+#undef F8S_COMPUTE
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (mt >= nstore) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = (first + mt) * 16 + g * 4 + reg;     // C/D layout: col = lane & 15, row = (lane >> 4)*4 + reg
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void k_proj_fwd_f8s(const unsigned char *__restrict__ F, int nrows, int D,
+                                                      const unsigned char *__restrict__ EtS, float *__restrict__ P, int PS,
+                                                      const float *__restrict__ pscale, int stagger) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_f8s[];   // 2 x NT*2048
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int T = (nrows + 15) >> 4;
+  const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
+  const int ntile = t1 - t0;                             // <= 16: the launcher sizes the grid for it
+  const int base = ntile >> 3, rem = ntile & 7;
+  const int nlive = base + (w < rem ? 1 : 0);            // this wave's row tiles (wave-uniform, 0..2)
+  const int first = t0 + w * base + (w < rem ? w : rem);
+  const unsigned char *arow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int tile = first + mt;
+    if (mt >= nlive) tile = nlive ? first + nlive - 1 : (T ? T - 1 : 0);     // never stored
+    int t = tile * 16 + r;
+    if (t >= nrows) t = nrows - 1;
+    arow[mt] = F + ((size_t)(t >> 5) * (size_t)(D >> 8)) * 8192 + (size_t)(t & 31) * 256 + g * 32;
+  }
+  const int nch = D >> 7;
+  const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
+  const float ps = *pscale;
+  if (nlive == 2) f8s_body<NT, 2>(arow, EtS, lds_f8s, nch, cshift, lane, P, PS, nrows, first, 2, ps);   // same barrier sequence
+  else f8s_body<NT, 1>(arow, EtS, lds_f8s, nch, cshift, lane, P, PS, nrows, first, nlive, ps);          // 0: a spare wave
+}
+
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
 __global__ __launch_bounds__(256) void k_reduce_parts(const float *__restrict__ part, int SK, int D, int d, int PS,
                                                       float *__restrict__ dEp, float gscale) {
@@ -1293,6 +1442,24 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
       return 0;
     }
   }
+  if constexpr (NT >= 10) {
+    // fp8 features, wide projection: ONE pass on the block-scaled fp8 MFMA (k_proj_fwd_f8s); BPRX_F8S=0 keeps the
+    // column-range passes of v8 for A/B measurements
+    const int f8s_on = getenv("BPRX_F8S") ? atoi(getenv("BPRX_F8S")) : 1;
+    if (f8 && v == 4 && f8s_on && h->EtS && h->cfg.feat_dim % 256 == 0) {
+      const int64_t T = (nrows + 15) / 16;
+      const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+      int64_t G = (T + 15) / 16;                              // at most 16 row tiles per workgroup (8 waves x 2)
+      if (G < ncu) G = T < ncu ? T : ncu;
+      else G = (G + ncu - 1) / ncu * ncu;
+      const size_t lds = (size_t)2 * NT * 2048;
+      auto kfn = k_proj_fwd_f8s<NT>;
+      (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(512), lds, s, (const unsigned char *)h->Ft, (int)nrows, h->cfg.feat_dim,
+                         (const unsigned char *)h->EtS, Pout, h->PS, pscale, stg & 1);
+      return 0;
+    }
+  }
   if (v == 4 && Deq % 256 == 0) {
     // v8 (one balanced workgroup per CU).  Projections wider than 9 column tiles (d > 143) are covered by two launches
     // over column ranges (F is read twice: still less time than one pass of the plain kernel).
@@ -1430,12 +1597,16 @@ int bprx_launch_cast_Et(bprx_handle *h, hipStream_t s) {
   BprxProfScope ps(h, BPRX_PHASE_CAST_ET, s);
   dim3 grid((D + 63) / 64, h->PS / 16);
   if (h->cfg.feat_dtype == BPRX_F_FP8) {
-    const int slot = h->qs_slot;                            // max|E,Bp| accumulates in qs[2 + slot] (zero: cleared a step ago)
+    const int slot = h->qs_slot;                            // max|E,Bp| sits / accumulates in qs[2 + slot]
     h->qs_slot ^= 1;
-    hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, h->t.E, (size_t)D * h->cfg.embed_d, h->t.Bp, (size_t)D,
-                       (uint32_t *)h->qs + 2 + slot);
-    hipLaunchKernelGGL(k_cast_Et8, grid, dim3(256), 0, s, h->t.E, h->t.Bp, (uint8_t *)h->Et, (uint8_t *)h->EtF, D,
-                       h->cfg.embed_d, h->PS, h->qs, h->cfg.feat_scale, slot);
+    if (!h->absmax_valid) {                                 // not left there by the last k_dense_update (first step, outside write)
+      BPRX_HIP(h, hipMemsetAsync((uint32_t *)h->qs + 2 + slot, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, h->t.E, (size_t)D * h->cfg.embed_d, h->t.Bp, (size_t)D,
+                         (uint32_t *)h->qs + 2 + slot);
+    }
+    h->absmax_valid = false;
+    hipLaunchKernelGGL(k_cast_Et8, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, s, h->t.E, h->t.Bp, (uint8_t *)h->Et,
+                       (uint8_t *)h->EtF, (uint8_t *)h->EtS, D, h->cfg.embed_d, h->PS, h->qs, h->cfg.feat_scale, slot);
     BPRX_LAUNCH_CHECK(h, "k_cast_Et8");
     return BPRX_OK;
   }

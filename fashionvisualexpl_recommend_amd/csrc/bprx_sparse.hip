@@ -522,6 +522,8 @@ __global__ void k_clear_flags(uint32_t *f, size_t n) {
 // The last kernel of a VBPR step also does the step's housekeeping, so that no separate launch has to:
 //   * bf16 features: the NEXT step's [E|Bp]^T images (chunk-major Et and fragment-major EtF, see k_cast_Et) are written
 //     from the updated values through an LDS transpose -- the step needs no k_cast_Et launch;
+//   * fp8 features: max|E,Bp| of the updated values goes to absmax_out (one atomicMax per block), so the next step's
+//     k_cast_Et8 needs no k_absmax launch in front of it;
 //   * list mode: the fp32 W rows of the listed items return to zero, their multiplicities are reset when nobody else does
 //     it, and the OTHER list cursor (the one the next list-mode step appends through) is cleared.
 constexpr int DU_KB = 8;
@@ -532,7 +534,8 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
                                                       double *__restrict__ sqpart, float gscale, uint16_t *__restrict__ Et,
                                                       uint16_t *__restrict__ EtF, const int32_t *__restrict__ ilist,
                                                       const int32_t *__restrict__ ilist_n, int32_t *__restrict__ ilist_n_next,
-                                                      int bound, float *__restrict__ W, int32_t *__restrict__ cnt_reset) {
+                                                      int bound, float *__restrict__ W, int32_t *__restrict__ cnt_reset,
+                                                      uint32_t *__restrict__ absmax_out) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[DU_KB][288];   // PS <= 272
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   if (ilist_n_next && blockIdx.x == 0 && threadIdx.x == 0) *ilist_n_next = 0;
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     }
   }
   double sq = 0.0;
+  uint32_t amax = 0;                                     // bit pattern of max|new value| (monotonic for non-negative floats)
   const size_t total = (size_t)D * PS;
   const int ntile = (D + DU_KB - 1) / DU_KB;
   for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
@@ -587,6 +591,8 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
           nv = pv - lr_t * gg;
         }
         *p = nv;
+        const uint32_t av = __float_as_uint(nv) & 0x7fffffffu;
+        amax = av > amax ? av : amax;
       }
       if (Et) tile[kr][n] = f2bf_s(nv);
     }
@@ -614,6 +620,18 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     __syncthreads();
   }
   if (threadIdx.x == 0) sqpart[blockIdx.x] = red[0];
+  if (absmax_out) {
+    __shared__ uint32_t wm[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(amax, o, 64); amax = v > amax ? v : amax; }
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t b = wm[0];
+      for (int q = 1; q < 4; ++q) b = wm[q] > b ? wm[q] : b;
+      if (b) atomicMax(absmax_out, b);
+    }
+  }
 }
 
 // loss = sum_b lossb[b] + reg*(||E||^2+||Bp||^2); fixed summation order (one block), double accumulation.
@@ -1118,8 +1136,11 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
                      h->cfg.epsilon, h->loss_acc, gscale, images ? (uint16_t *)h->Et : (uint16_t *)nullptr, (uint16_t *)h->EtF,
                      lm ? (const int32_t *)h->ilist : (const int32_t *)nullptr, (const int32_t *)h->list_cur,
                      lm ? h->ilist_n + (h->list_slot ^ 1) : (int32_t *)nullptr, (int)bound, h->W,
-                     (lm && h->list_reset_cnt) ? h->cntI : (int32_t *)nullptr);
+                     (lm && h->list_reset_cnt) ? h->cntI : (int32_t *)nullptr,
+                     // fp8: the slot the next k_cast_Et8 reads (cleared by the last one)
+                     h->cfg.feat_dtype == BPRX_F_FP8 ? (uint32_t *)h->qs + 2 + h->qs_slot : (uint32_t *)nullptr);
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
+  h->absmax_valid = h->cfg.feat_dtype == BPRX_F_FP8;
   if (lm) { h->list_slot ^= 1; h->list_mode = 0; }      // the step's list is consumed
   h->et_valid = images;                                 // E / Bp moved: the images were refreshed here, or are stale
   h->p_valid = false;                                   //               the item projections are stale

@@ -94,6 +94,14 @@ def test_wide_projection_column_range_passes_match_the_plain_kernel(monkeypatch,
     t = _state(I, d, fp8, seed=d)
     plain = _scores(monkeypatch, 0, I, d, fp8, t)
     got = _scores(monkeypatch, 4, I, d, fp8, t)
+    tol = 2e-6 * float(plain.abs().max()) + 1e-9
+    if fp8:
+        # fp8 wide projections run ONE pass of k_proj_fwd_f8s on the block-scaled MFMA (K = 128 per instruction, unit
+        # scales): same products, another fp32 summation order inside the instruction -> tolerance, not bit equality
+        assert float((got - plain).abs().max()) <= tol, (d, float((got - plain).abs().max()), tol)
+        monkeypatch.setenv("BPRX_F8S", "0")                # ... and the column-range passes of v8 stay bit-exact
+        got = _scores(monkeypatch, 4, I, d, fp8, t)
+        monkeypatch.delenv("BPRX_F8S")
     assert torch.equal(got, plain), (d, fp8, int((got != plain).sum()))
     stag = _scores(monkeypatch, 12, I, d, fp8, t)
-    assert float((stag - plain).abs().max()) <= 2e-6 * float(plain.abs().max()) + 1e-9
+    assert float((stag - plain).abs().max()) <= tol
