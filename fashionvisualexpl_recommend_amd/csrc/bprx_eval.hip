@@ -88,7 +88,7 @@ constexpr int EVMAX = 32;   // held-out items per user handled on the device (th
 __global__ __launch_bounds__(256) void k_eval_users(const float *__restrict__ S, int u0, int I,
                                                     const int64_t *__restrict__ tr_ptr, const int32_t *__restrict__ tr_items,
                                                     const int64_t *__restrict__ ev_ptr, const int32_t *__restrict__ ev_items,
-                                                    int K, double *__restrict__ out) {
+                                                    int K, double *__restrict__ out, int32_t *__restrict__ errflag) {
   __shared__ float sp[EVMAX];
   __shared__ int ev[EVMAX];
   __shared__ int cnt_all[EVMAX], cnt_sub[EVMAX];
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void k_eval_users(const float *__restrict__ S,
     return;
   }
   if (tid < nev) {
-    const int it = ev_items[e0 + tid];
+    int it = ev_items[e0 + tid];
+    if ((unsigned)it >= (unsigned)I) { *errflag = 5; it = 0; }      // reported by bprx_sync_check, never dereferenced
     ev[tid] = it;
     sp[tid] = s[it];
     cnt_all[tid] = 0;
@@ -155,7 +156,122 @@ __global__ __launch_bounds__(256) void k_eval_users(const float *__restrict__ S,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Evaluator.store_recommendation on the device (Evaluator.py:225-239): per user, the train items are masked with -inf
+// IN the score row (as the reference does: results[u][training_list[u]] = -np.inf) and the K largest scores are
+// selected.  One workgroup per user: radix select of the K-th largest key over the row (four 8-bit histogram passes on
+// the order-preserving integer image of the fp32 scores; the row is L2-resident), one collection pass, and a bitonic
+// sort of the K candidates by (score descending, item ascending).
+// The reference orders equal scores by numpy's unstable argsort (implementation- and CPU-dependent); rows whose output
+// depends on such a tie -- equal scores among the K selected, or at the selection boundary, or fewer than K unmasked
+// items -- are FLAGGED (flag[row] = 1) so that the caller can redo exactly those rows with numpy on the (masked) row.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX = 1024;
+
+__device__ __forceinline__ uint32_t f2key(float x) {       // larger float <-> larger key; -inf is the smallest finite-order key
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_topk(float *__restrict__ S, int u0, int I, const int64_t *__restrict__ tr_ptr,
+                                              const int32_t *__restrict__ tr_items, int K, int32_t *__restrict__ idx_out,
+                                              float *__restrict__ val_out, int32_t *__restrict__ flag_out) {
+  __shared__ int hist[256];
+  __shared__ uint32_t s_prefix, s_mask;
+  __shared__ int s_remaining, s_ngt, s_neq, s_bad;
+  __shared__ uint32_t ckey[TOPK_MAX];
+  __shared__ int cidx[TOPK_MAX];
+  const int u = u0 + blockIdx.x, tid = threadIdx.x;
+  float *s = S + (size_t)blockIdx.x * I;
+  const int64_t t0 = tr_ptr[u];
+  const int ntr = (int)(tr_ptr[u + 1] - t0);
+  for (int q = tid; q < ntr; q += 256) {
+    const int it = tr_items[t0 + q];
+    if ((unsigned)it < (unsigned)I) s[it] = -INFINITY;
+  }
+  const int Kc = K < I ? K : I;                            // argsort()[-k:] returns min(k, I) entries
+  if (tid == 0) { s_prefix = 0; s_mask = 0; s_remaining = Kc; s_ngt = 0; s_neq = 0; s_bad = K > I ? 1 : 0; }
+  __syncthreads();
+  for (int pass = 3; pass >= 0; --pass) {
+    hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix, mask = s_mask;
+    for (int i = tid; i < I; i += 256) {
+      const uint32_t key = f2key(s[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rem = s_remaining, b = 255;
+      for (; b > 0; --b) {                                  // from the largest byte value down
+        if (hist[b] >= rem) break;
+        rem -= hist[b];
+      }
+      s_remaining = rem;                                    // still wanted among the elements whose byte == b
+      s_prefix = prefix | ((uint32_t)b << (8 * pass));
+      s_mask = mask | (255u << (8 * pass));
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_prefix;                            // key of the K-th largest score; `want_eq` of the elements equal to
+  const int want_eq = s_remaining;                          // it belong to the list, all Kc - want_eq larger ones do
+  for (int i = tid; i < I; i += 256) {
+    const uint32_t key = f2key(s[i]);
+    if (key > kth) {
+      const int p = atomicAdd(&s_ngt, 1);
+      ckey[p] = key; cidx[p] = i;
+    } else if (key == kth) {
+      const int e = atomicAdd(&s_neq, 1);                   // more than want_eq of them: a tie straddles the boundary (flagged)
+      if (e < want_eq) { ckey[Kc - want_eq + e] = key; cidx[Kc - want_eq + e] = i; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && (s_neq != want_eq || kth == f2key(-INFINITY))) s_bad = 1;   // boundary tie / masked items reach the list
+  __syncthreads();
+  // bitonic sort of the Kc candidates by (key descending, item ascending), padded to a power of two with minimal keys
+  int n2 = 1;
+  while (n2 < Kc) n2 <<= 1;
+  for (int q = Kc + tid; q < n2; q += 256) { ckey[q] = 0u; cidx[q] = 0x7fffffff; }
+  __syncthreads();
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int q = tid; q < n2; q += 256) {
+        const int partner = q ^ stride;
+        if (partner > q) {
+          const bool desc = (q & size) == 0;                // first half of each `size` block sorted "better first"
+          const uint32_t ka = ckey[q], kb = ckey[partner];
+          const int ia = cidx[q], ib = cidx[partner];
+          const bool a_better = ka > kb || (ka == kb && ia < ib);
+          if (a_better != desc) { ckey[q] = kb; ckey[partner] = ka; cidx[q] = ib; cidx[partner] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int q = tid; q < Kc; q += 256) {
+    if (q + 1 < Kc && ckey[q] == ckey[q + 1]) s_bad = 1;    // equal scores inside the list: numpy's order is unspecified
+    idx_out[(size_t)blockIdx.x * K + q] = cidx[q];
+    val_out[(size_t)blockIdx.x * K + q] = s[cidx[q]];
+  }
+  for (int q = Kc + tid; q < K; q += 256) { idx_out[(size_t)blockIdx.x * K + q] = -1; val_out[(size_t)blockIdx.x * K + q] = 0.f; }
+  __syncthreads();
+  if (tid == 0) flag_out[blockIdx.x] = s_bad;
+}
+
 }  // namespace
+
+extern "C" int bprx_topk(bprx_handle *h, int32_t u0, int32_t u1, float *scores, const int64_t *train_ptr,
+                         const int32_t *train_items, int32_t K, int32_t *idx, float *val, int32_t *flag, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (u0 < 0 || u1 > h->cfg.num_users || u0 > u1 || !scores || !train_ptr || !train_items || !idx || !val || !flag)
+    BPRX_FAIL(h, BPRX_E_INVALID, "topk: bad argument");
+  if (K <= 0 || K > TOPK_MAX) BPRX_FAIL(h, BPRX_E_INVALID, "topk: K=%d outside [1, %d]", K, TOPK_MAX);
+  if (u0 == u1) return BPRX_OK;
+  hipLaunchKernelGGL(k_topk, dim3(u1 - u0), dim3(256), 0, (hipStream_t)stream, scores, u0, h->cfg.num_items, train_ptr,
+                     train_items, K, idx, val, flag);
+  BPRX_LAUNCH_CHECK(h, "k_topk");
+  return BPRX_OK;
+}
 
 // used by bprx_score_block when the factor widths allow the MFMA path (K step of 2)
 int bprx_launch_score_gemm(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s) {
@@ -177,7 +293,7 @@ extern "C" int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const flo
     BPRX_FAIL(h, BPRX_E_INVALID, "eval_users: bad argument");
   if (u0 == u1) return BPRX_OK;
   hipLaunchKernelGGL(k_eval_users, dim3(u1 - u0), dim3(256), 0, (hipStream_t)stream, scores, u0, h->cfg.num_items, train_ptr,
-                     train_items, eval_ptr, eval_items, K, out);
+                     train_items, eval_ptr, eval_items, K, out, h->errflag);
   BPRX_LAUNCH_CHECK(h, "k_eval_users");
   return BPRX_OK;
 }

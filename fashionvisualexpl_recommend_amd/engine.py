@@ -207,6 +207,16 @@ class Engine:
                                                     _ptr(eval_csr[0]), _ptr(eval_csr[1]), int(K), _ptr(out), _stream()))
         return out
 
+    def topk(self, u0, u1, scores, train_csr, K):
+        """bprx_topk: masks the train items IN `scores` and returns (idx int32 [n,K], val fp32 [n,K], flag int32 [n])."""
+        n = u1 - u0
+        idx = torch.empty((n, K), dtype=torch.int32, device=self.device)
+        val = torch.empty((n, K), dtype=torch.float32, device=self.device)
+        flag = torch.empty(n, dtype=torch.int32, device=self.device)
+        _ffi.check(self.h, self.lib.bprx_topk(self.h, u0, u1, _ptr(scores), _ptr(train_csr[0]), _ptr(train_csr[1]), int(K),
+                                              _ptr(idx), _ptr(val), _ptr(flag), _stream()))
+        return idx, val, flag
+
     def profile(self, on):
         _ffi.check(self.h, self.lib.bprx_profile_enable(self.h, 1 if on else 0))
 

@@ -79,8 +79,10 @@ class Evaluator:
             yield u0, self.model.predict_block(u0, u1)
 
     # ---- device path (libbprx bprx_score_block + bprx_eval_users): used whenever the model runs on the engine ----
-    def _device_csr(self, lists, device):
+    def _device_csr(self, lists, device, dedup=False):
         import torch
+        if dedup:       # the reference masks with set(training_list[user]) (Evaluator.py:41): a repeated row counts once
+            lists = [list(dict.fromkeys(l)) for l in lists]
         indptr = np.zeros(len(lists) + 1, dtype=np.int64)
         for u, l in enumerate(lists):
             indptr[u + 1] = indptr[u] + len(l)
@@ -92,13 +94,7 @@ class Evaluator:
     def _metrics_device(self):
         import torch
         eng = self.model.engine
-        if getattr(self, "_csr", None) is None:
-            U = self.model.data.num_users
-            pad = lambda l: list(l[:U]) + [[] for _ in range(U - len(l))]
-            self._csr = {"train": self._device_csr(pad(self.data.training_list), eng.device),
-                         "test": self._device_csr(pad(self.data.test_list), eng.device),
-                         "val": self._device_csr(pad(self.data.validation_list), eng.device)
-                         if self.data.validation_list else None}
+        self._metrics_device_csr()
         U = self.model.data.num_users
         rows = {"test": [], "val": []}
         for u0 in range(0, U, self.user_block):
@@ -161,8 +157,48 @@ class Evaluator:
         }                                   # 'auc_t': auc_v is the reference's own aliasing (Evaluator.py:220)
         return print_results
 
+    def _store_recommendation_device(self, out):
+        """bprx_score_block + bprx_topk per user block; only rows whose list depends on the order of EQUAL scores (flagged
+        by the kernel: the reference's order there is numpy's unstable argsort) are redone on the host, from the row the
+        kernel has already masked."""
+        eng = self.model.engine
+        self._metrics_device_csr()
+        U = self.model.data.num_users
+        for u0 in range(0, U, self.user_block):
+            u1 = min(U, u0 + self.user_block)
+            sc = eng.score_block(u0, u1)
+            idx, val, flag = eng.topk(u0, u1, sc, self._csr["train"], self.k)
+            idx, val, flag = idx.cpu().numpy(), val.cpu().numpy(), flag.cpu().numpy()
+            redo = np.nonzero(flag)[0]
+            rows = {int(r): sc[int(r)].cpu().numpy() for r in redo}          # few: ties are rare in real-valued scores
+            for r in range(u1 - u0):
+                u = u0 + r
+                if r in rows:
+                    row = rows[r]
+                    top_k_id = row.argsort()[-self.k:][::-1]
+                    top_k_score = row[top_k_id]
+                else:
+                    kk = min(self.k, idx.shape[1], sc.shape[1])
+                    top_k_id, top_k_score = idx[r, :kk], val[r, :kk]
+                for i, value in enumerate(top_k_id):
+                    out.write(str(u) + '\t' + str(value) + '\t' + str(top_k_score[i]) + '\n')
+
+    def _metrics_device_csr(self):
+        if getattr(self, "_csr", None) is None:
+            eng = self.model.engine
+            U = self.model.data.num_users
+            pad = lambda l: list(l[:U]) + [[] for _ in range(U - len(l))]
+            self._csr = {"train": self._device_csr(pad(self.data.training_list), eng.device, dedup=True),
+                         "test": self._device_csr(pad(self.data.test_list), eng.device),
+                         "val": self._device_csr(pad(self.data.validation_list), eng.device)
+                         if self.data.validation_list else None}
+
     def store_recommendation(self, path=""):
         """Evaluator.py:225-239: per user mask train items, top-k by argsort, 'u\\titem\\tscore' rows."""
+        if getattr(self.model, "engine", None) is not None and not getattr(self, "force_host", False) and self.k <= 1024:
+            with open(path, 'w') as out:
+                self._store_recommendation_device(out)
+            return
         with open(path, 'w') as out:
             for u0, sc in self._score_blocks():
                 for r in range(sc.shape[0]):

@@ -198,6 +198,16 @@ BPRX_API int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const float
    instantiation against the plain kernel. */
 BPRX_API int bprx_kernel_variant_safe(int ver, int nt, int mt, int rem);
 
+/* Evaluator.store_recommendation on the device (Evaluator.py:225-239) for users [u0,u1): the train items of each user are
+   overwritten with -inf IN `scores` (the output of bprx_score_block for the same range; the reference does the same to its
+   score matrix, :233) and the K (<= 1024) largest remaining scores are returned best first: idx int32 [(u1-u0), K] (-1 past
+   min(K, I)), val fp32 same shape.  flag int32 [(u1-u0)]: 1 = the row's list depends on how EQUAL scores are ordered (ties
+   inside the list or at its boundary, or fewer than K unmasked items) -- the reference's order there is numpy's unstable
+   argsort; the caller redoes flagged rows with numpy on the (already masked) row.  Unflagged rows equal the reference's
+   output exactly.  CSR as in bprx_eval_users. */
+BPRX_API int bprx_topk(bprx_handle *h, int32_t u0, int32_t u1, float *scores, const int64_t *train_ptr,
+                       const int32_t *train_items, int32_t K, int32_t *idx, float *val, int32_t *flag, void *stream);
+
 /* Measurement helper (bench.py): one launch of a plain streaming-read kernel over buf[0, bytes) (device memory, >= 64 MiB;
    sink: >= 8 KiB of device scratch).  Returns the number of bytes the launch reads, or a negative BPRX_E_* code.  Timed by
    the caller on `stream`: the rate this device's HBM delivers to a streaming kernel, quoted beside the 8 TB/s spec. */
