@@ -12,12 +12,13 @@ LIB_PATH = os.path.join(HERE, "libbprx.so")
 ABI_VERSION = 4
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2
+FLAG_DENSE_ALLREDUCE = 4
 
 MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
 FEAT_DTYPE = {"fp32": 0, "bf16": 1, "fp8": 2}
 E_RANGE = -4
-PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count"]
+PHASES = ["cast_Et", "proj_fwd", "triplet_grad", "proj_bwd", "reduce_parts", "apply", "dense_update", "loss_reduce", "item_seg", "seg_alloc", "row_count", "adam_catchup"]
 
 
 class BprxError(RuntimeError):
@@ -70,6 +71,7 @@ def lib():
         "bprx_kernel_variant_safe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "bprx_set_adam_step": (C.c_int, [vp, i64]),
         "bprx_get_adam_step": (i64, [vp]),
+        "bprx_sync_adam": (C.c_int, [vp, vp]),
         "bprx_score_pairs": (C.c_int, [vp, vp, vp, i64, vp, vp]),
         "bprx_step": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
         "bprx_step_begin": (C.c_int, [vp, vp, vp, vp, i64, vp]),
@@ -108,7 +110,7 @@ def lib():
 
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
-           "bprx_set_adam_step", "bprx_get_adam_step", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
+           "bprx_set_adam_step", "bprx_get_adam_step", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",

@@ -26,7 +26,7 @@ static void graph_drop(bprx_handle *h) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -58,8 +58,11 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       CFAIL(BPRX_E_INVALID, "fp8 features need feat_dim %% 256 == 0 (got %d)", cfg->feat_dim);
     if (cfg->feat_dtype == BPRX_F_FP8 && !(cfg->feat_scale > 0.f)) CFAIL(BPRX_E_INVALID, "fp8 features need feat_scale > 0");
   }
-  if ((cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) && cfg->optimizer != BPRX_OPT_SGD)
-    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_*_GRAD support optimizer sgd only");
+  if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->optimizer != BPRX_OPT_SGD)
+    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD supports optimizer sgd only");
+  if ((cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) && cfg->optimizer != BPRX_OPT_SGD &&
+      getenv("BPRX_ADAM_LAZY") && atoi(getenv("BPRX_ADAM_LAZY")) == 0)
+    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_USER_GRAD with adam_tf23 needs the lazy form (BPRX_ADAM_LAZY != 0)");
   if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->model != BPRX_MODEL_BPRMF)
     CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD is for BPRMF (VBPR keeps its items and features local)");
   hipError_t e = hipSetDevice(cfg->device);
@@ -172,6 +175,17 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     }
   }
   h->SK_step = h->SK;
+  // adam_tf23: lazy-exact form by default (rows are replayed when read; BPRX_ADAM_LAZY=0 = the whole-table sweeps)
+  h->adam_lazy = cfg->optimizer == BPRX_OPT_ADAM_TF23 && !(getenv("BPRX_ADAM_LAZY") && atoi(getenv("BPRX_ADAM_LAZY")) == 0);
+  if (h->adam_lazy) {
+    if (dalloc_zero(&h->lastU, U) != hipSuccess || dalloc_zero(&h->lastI, I) != hipSuccess ||
+        dalloc_zero(&h->lr_hist, (size_t)bprx_adam_hist()) != hipSuccess) {
+      snprintf(g_create_err, sizeof(g_create_err), "adam bookkeeping allocation failed");
+      free_scratch(h);
+      delete h;
+      return BPRX_E_NOMEM;
+    }
+  }
   // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
   h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;   // per side: make_args
   if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
@@ -262,13 +276,13 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
     if (rc) return rc;
   }
   h->bound = true;
-  return BPRX_OK;
+  return bprx_launch_adam_reset(h, h->adam_t, 0);   // every bound row counts as current at optimizer.iterations
 }
 
 extern "C" int bprx_tables_dirty(bprx_handle *h) {
   if (!h) return BPRX_E_INVALID;
   h->et_valid = h->p_valid = h->absmax_valid = false;
-  return BPRX_OK;
+  return h->bound ? bprx_launch_adam_reset(h, h->adam_t, 0) : BPRX_OK;   // outside values are current by definition
 }
 
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
@@ -284,7 +298,7 @@ extern "C" int bprx_set_hyper(bprx_handle *h, float lr, float reg) {
 extern "C" int bprx_set_adam_step(bprx_handle *h, int64_t it) {
   if (!h || it < 0) return BPRX_E_INVALID;
   h->adam_t = it;
-  return BPRX_OK;
+  return h->bound ? bprx_launch_adam_reset(h, it, 0) : BPRX_OK;
 }
 
 extern "C" int64_t bprx_get_adam_step(const bprx_handle *h) { return h ? h->adam_t : -1; }
@@ -296,12 +310,19 @@ static int check_ready(bprx_handle *h, int64_t B) {
   return BPRX_OK;
 }
 
+extern "C" int bprx_sync_adam(bprx_handle *h, void *stream) {
+  int rc = check_ready(h, 0);
+  if (rc) return rc;
+  return bprx_launch_adam_sync(h, h->adam_t, (hipStream_t)stream);
+}
+
 extern "C" int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32_t *item, int64_t B, float *x, void *stream) {
   int rc = check_ready(h, B);
   if (rc) return rc;
   if (B == 0) return BPRX_OK;
   if (!user || !item || !x) BPRX_FAIL(h, BPRX_E_INVALID, "score_pairs: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = bprx_launch_adam_sync(h, h->adam_t, s))) return rc;          // lazy adam: the rows must be current
   if (h->cfg.model == BPRX_MODEL_VBPR) {
     if (h->p_valid) return bprx_launch_score(h, user, item, B, nullptr, 0, x, s);      // every item's projection is at hand
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
@@ -319,6 +340,18 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  float lr_t = h->cfg.lr;
+  if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
+    h->adam_t += 1;
+    float t = (float)h->adam_t;
+    lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
+    if (h->adam_lazy) {
+      // the ring holds lr_s of the last ADAM_HIST steps: before it would wrap, everything is caught up (amortised: one
+      // sweep per ~8000 steps); then the rows of THIS batch are brought to step t-1 for the forward pass
+      if (h->adam_t - h->adam_synced >= bprx_adam_hist() - 2 && (rc = bprx_launch_adam_sync(h, h->adam_t - 1, s))) return rc;
+      if ((rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, s))) return rc;
+    }
+  }
   // list mode: both projections over the batch's distinct items only (needs the index pass BEFORE the forward projection)
   h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 4 * B <= (int64_t)h->cfg.num_items));
   h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
@@ -345,15 +378,9 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (fork_index) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
   else if (!h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
-  if ((rc = bprx_launch_item_seg(h, pos, neg, B, h->cfg.lr, s))) return rc;             // item rows + W, no float atomics
+  if ((rc = bprx_launch_item_seg(h, pos, neg, B, lr_t, s))) return rc;                  // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
   // projection -- with VBPR it runs on the side stream beside it
-  float lr_t = h->cfg.lr;
-  if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
-    h->adam_t += 1;
-    float t = (float)h->adam_t;
-    lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
-  }
   if (vb && h->side && h->side_mode == 1) {
     BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
     BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -512,6 +539,7 @@ extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *o
   if (u0 < 0 || u1 > h->cfg.num_users || u0 > u1 || !out) BPRX_FAIL(h, BPRX_E_INVALID, "score_block: bad user range [%d,%d)", u0, u1);
   if (u0 == u1) return BPRX_OK;
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = bprx_launch_adam_sync(h, h->adam_t, s))) return rc;          // lazy adam: predict_all reads every row
   if (h->cfg.model == BPRX_MODEL_VBPR && !h->p_valid) {   // P = F.[E|Bp] once per parameter state, not once per user block
     if ((rc = bprx_launch_cast_Et(h, s))) return rc;
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;

@@ -16,6 +16,11 @@ struct bprx_handle {
   bprx_tables t;
   bool bound;
   int64_t adam_t;          // optimizer.iterations
+  // lazy-exact adam_tf23 (bprx_sparse.hip): rows are brought up to date when they are read
+  bool adam_lazy;
+  int32_t *lastU, *lastI;  // [U], [I] step up to which the row (Gu/Tu resp. Gi/Bi and their slots) is current
+  float *lr_hist;          // ring of the last ADAM_HIST steps' lr_t
+  int64_t adam_synced;     // every row is current at least up to this step
   char err[512];
 
   // ---- scratch owned by the handle (device) ----
@@ -134,6 +139,11 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
 int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
                       float lr_t, hipStream_t s);
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s);
+int bprx_launch_adam_catchup(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t,
+                             hipStream_t s);
+int bprx_launch_adam_sync(bprx_handle *h, int64_t t, hipStream_t s);
+int bprx_launch_adam_reset(bprx_handle *h, int64_t t, hipStream_t s);
+int bprx_adam_hist(void);
 int bprx_launch_loss_reduce(bprx_handle *h, int64_t B, float *loss_out, hipStream_t s);
 int bprx_launch_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);
 int bprx_launch_score_gemm(bprx_handle *h, int32_t u0, int32_t u1, float *out, hipStream_t s);

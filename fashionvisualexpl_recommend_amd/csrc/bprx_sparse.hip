@@ -494,19 +494,246 @@ __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *
   if (kind != 0 && lane == 0) { Bi[row] -= lr * a.dBi[row]; a.dBi[row] = 0.f; }
 }
 
-// adam_tf23, sparse-variable rule applied to the WHOLE table (TF-2.3 Keras Adam is not lazy):
+// adam_tf23, sparse-variable rule (TF-2.3 Keras Adam is NOT lazy: every row of the table decays and moves every step):
 //   m = m*b1 + g*(1-b1); v = v*b2 + g*g*(1-b2); var -= lr_t*m/(sqrt(v)+eps)     (g == 0 on untouched rows)
+// One element, one step.  The whole-table sweep and the lazy catch-up replay share this function, so that a replayed
+// step performs bit for bit the arithmetic the sweep would have performed.
+__device__ __forceinline__ void adam_elem(float &p, float &m, float &v, float g, float b1, float b2, float lr_t, float eps) {
+#pragma clang fp contract(off)   // no fused multiply-adds: the same roundings wherever this is inlined (scalar sweep, float4 replay)
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const float mt = m * b1 + g * omb1;
+  const float vt = v * b2 + (g * g) * omb2;
+  m = mt; v = vt;
+  p = p - lr_t * mt / (sqrtf(vt) + eps);
+}
+
 __global__ __launch_bounds__(256) void k_adam_sparse(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
                                                      float *__restrict__ g, size_t n, float b1, float b2, float lr_t, float eps) {
-  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-    float gg = g[e];
-    float mt = m[e] * b1 + gg * omb1;
-    float vt = v[e] * b2 + (gg * gg) * omb2;
-    m[e] = mt; v[e] = vt;
-    p[e] = p[e] - lr_t * mt / (sqrtf(vt) + eps);
+    float pp = p[e], mm = m[e], vv = v[e];
+    adam_elem(pp, mm, vv, g[e], b1, b2, lr_t, eps);
+    p[e] = pp; m[e] = mm; v[e] = vv;
     g[e] = 0.f;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LAZY-EXACT adam_tf23.  The sweep above moves 6*(U+I)*(k+d)*4 bytes per step whatever the batch.  A row that
+// receives no gradient in a step still changes (m, v decay; var moves by lr_s*m/(sqrt(v)+eps)), but by a recurrence that
+// depends only on the row's own (p, m, v) and on the step's lr_s -- so it can be REPLAYED later, exactly: last[row] = the
+// step up to which the row is current; before a row is read (forward pass of a batch that uses it, bprx_score_*,
+// bprx_sync_adam) the skipped steps last+1 .. t are replayed in registers with g = 0 through adam_elem(), the very
+// function the sweep uses.  lr_s of the last ADAM_HIST steps is kept in a device ring (written by the step's catch-up
+// kernel); the host forces a full catch-up sweep before the ring would wrap.  Rows with m = v = 0 (never touched) are
+// fixed points of the recurrence and are skipped.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ADAM_HIST = 8192;
+
+struct AdamLazy {
+  float b1, b2, eps;
+  const float *lr_hist;          // lr_s at lr_hist[s & (ADAM_HIST - 1)]
+};
+
+// lr_s for s = from+1 .. to without a global load per step: lane l of the G-lane group fetches lr_{from+1+l} (+ a window of
+// G steps at a time), the step loop reads it with a shuffle.  (A load of lr_hist[s] inside the per-element recurrence put
+// an L2 round trip into every step of the chain: 122 us for the C2 catch-up instead of ~20.)
+template <int G>
+struct LrWindow {
+  const AdamLazy &a;
+  int from, lane, base;
+  float mine;
+  __device__ __forceinline__ LrWindow(const AdamLazy &a_, int from_, int lane_) : a(a_), from(from_), lane(lane_), base(from_ + 1) {
+    mine = a.lr_hist[(base + lane) & (ADAM_HIST - 1)];
+  }
+  __device__ __forceinline__ float at(int s) {            // s ascending, called by all G lanes together
+    if (s - base >= G) { base += G; mine = a.lr_hist[(base + lane) & (ADAM_HIST - 1)]; }
+    return __shfl(mine, s - base, G);
+  }
+};
+template <>
+struct LrWindow<1> {
+  const AdamLazy &a;
+  __device__ __forceinline__ LrWindow(const AdamLazy &a_, int, int) : a(a_) {}
+  __device__ __forceinline__ float at(int s) { return a.lr_hist[s & (ADAM_HIST - 1)]; }
+};
+
+// replay steps from+1 .. to on up to two rows of a table pair (user: Gu + Tu; item: Gi) of n0 / n1 floats, steps OUTER
+// (one lr per step for all elements).  VEC (n % 4 == 0): lane l of the G-lane group owns float4 l of each row (n <= 4G);
+// else elements l, l+G, ... are handled row by row with the scalar form.
+template <int G, bool VEC>
+__device__ __forceinline__ void adam_replay_rows(float *p0, float *m0, float *v0, int n0, float *p1, float *m1, float *v1, int n1,
+                                                 int lane, int from, int to, const AdamLazy &a) {
+  if (VEC && n0 <= 4 * G && n1 <= 4 * G) {
+    const int c = lane * 4;
+    const bool h0 = c < n0, h1 = c < n1;
+    float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), mm0 = pp0, vv0 = pp0, pp1 = pp0, mm1 = pp0, vv1 = pp0;
+    if (h0) { pp0 = ld4(p0 + c); mm0 = ld4(m0 + c); vv0 = ld4(v0 + c); }
+    if (h1) { pp1 = ld4(p1 + c); mm1 = ld4(m1 + c); vv1 = ld4(v1 + c); }
+    // rows whose m and v are all zero (never touched) are fixed points of the recurrence: p - lr*0/(0 + eps) == p
+    const bool nz = mm0.x != 0.f || mm0.y != 0.f || mm0.z != 0.f || mm0.w != 0.f || vv0.x != 0.f || vv0.y != 0.f || vv0.z != 0.f ||
+                    vv0.w != 0.f || mm1.x != 0.f || mm1.y != 0.f || mm1.z != 0.f || mm1.w != 0.f || vv1.x != 0.f || vv1.y != 0.f ||
+                    vv1.z != 0.f || vv1.w != 0.f;
+    const unsigned long long bal = __ballot(nz);
+    const unsigned long long gm = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << ((threadIdx.x & 63) / G * G));
+    if ((bal & gm) == 0ull) return;                          // group-uniform
+    LrWindow<G> lw(a, from, lane);
+    for (int s = from + 1; s <= to; ++s) {
+      const float lr = lw.at(s);
+      adam_elem(pp0.x, mm0.x, vv0.x, 0.f, a.b1, a.b2, lr, a.eps); adam_elem(pp0.y, mm0.y, vv0.y, 0.f, a.b1, a.b2, lr, a.eps);
+      adam_elem(pp0.z, mm0.z, vv0.z, 0.f, a.b1, a.b2, lr, a.eps); adam_elem(pp0.w, mm0.w, vv0.w, 0.f, a.b1, a.b2, lr, a.eps);
+      if (n1) {
+        adam_elem(pp1.x, mm1.x, vv1.x, 0.f, a.b1, a.b2, lr, a.eps); adam_elem(pp1.y, mm1.y, vv1.y, 0.f, a.b1, a.b2, lr, a.eps);
+        adam_elem(pp1.z, mm1.z, vv1.z, 0.f, a.b1, a.b2, lr, a.eps); adam_elem(pp1.w, mm1.w, vv1.w, 0.f, a.b1, a.b2, lr, a.eps);
+      }
+    }
+    if (h0) { *reinterpret_cast<float4 *>(p0 + c) = pp0; *reinterpret_cast<float4 *>(m0 + c) = mm0; *reinterpret_cast<float4 *>(v0 + c) = vv0; }
+    if (h1) { *reinterpret_cast<float4 *>(p1 + c) = pp1; *reinterpret_cast<float4 *>(m1 + c) = mm1; *reinterpret_cast<float4 *>(v1 + c) = vv1; }
+    return;
+  }
+  for (int which = 0; which < 2; ++which) {
+    float *p = which ? p1 : p0, *m = which ? m1 : m0, *v = which ? v1 : v0;
+    const int n = which ? n1 : n0;
+    for (int c0 = 0; c0 < n; c0 += G) {                   // all G lanes walk the steps together (shuffles), masked past the end
+      const int c = c0 + lane;
+      float pp = 0.f, mm = 0.f, vv = 0.f;
+      if (c < n) { pp = p[c]; mm = m[c]; vv = v[c]; }
+      if (G > 1) {
+        const unsigned long long bal = __ballot(mm != 0.f || vv != 0.f);
+        const unsigned long long gm = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << ((threadIdx.x & 63) / G * G));
+        if ((bal & gm) == 0ull) continue;                    // group-uniform
+      } else if (mm == 0.f && vv == 0.f) continue;
+      LrWindow<G> lw(a, from, lane);
+      for (int s = from + 1; s <= to; ++s) adam_elem(pp, mm, vv, 0.f, a.b1, a.b2, lw.at(s), a.eps);
+      if (c < n) { p[c] = pp; m[c] = mm; v[c] = vv; }
+    }
+  }
+}
+
+struct AdamTables {
+  float *Gu, *mGu, *vGu, *Tu, *mTu, *vTu, *Gi, *mGi, *vGi, *Bi, *mBi, *vBi;
+  int32_t *lastU, *lastI;
+  int U, I, k, d;
+};
+
+// all rows of one user (Gu, Tu) or one item (Gi, Bi) from step `from` to step `to`
+template <int G, bool VEC>
+__device__ __forceinline__ void adam_replay_kind(const AdamTables &T, bool usr, int row, int lane, int from, int to, const AdamLazy &a) {
+  if (usr) {
+    const size_t ok = (size_t)row * T.k, od = (size_t)row * T.d;
+    adam_replay_rows<G, VEC>(T.Gu + ok, T.mGu + ok, T.vGu + ok, T.k, T.d ? T.Tu + od : nullptr, T.d ? T.mTu + od : nullptr,
+                             T.d ? T.vTu + od : nullptr, T.d, lane, from, to, a);
+  } else {
+    const size_t ok = (size_t)row * T.k;
+    adam_replay_rows<G, VEC>(T.Gi + ok, T.mGi + ok, T.vGi + ok, T.k, nullptr, nullptr, nullptr, 0, lane, from, to, a);
+    if (lane == 0) adam_replay_rows<1, false>(T.Bi + row, T.mBi + row, T.vBi + row, 1, nullptr, nullptr, nullptr, 0, 0, from, to, a);
+  }
+}
+
+// Before the forward pass of step t: every row the batch uses is brought to step t-1.  One lane group per occurrence
+// (kind 0 user, 1 positive item, 2 negative item); the group that raises last[row] to t-1 first owns the replay, the
+// others find it done (the rows are read by the NEXT kernel).  Block 0 also records lr_t of this step in the ring.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_adam_catchup(AdamTables T, AdamLazy a, const int32_t *__restrict__ user,
+                                                      const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
+                                                      int64_t B, int t, float lr_t, float *__restrict__ lr_hist_w) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) lr_hist_w[t & (ADAM_HIST - 1)] = lr_t;
+  const int64_t job = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  const bool valid = job < 3 * B;
+  const int kind = valid ? (int)(job / B) : 0;
+  const int64_t b = valid ? job - (int64_t)kind * B : 0;
+  const int row = kind == 0 ? clamp_quiet(user[b], T.U) : clamp_quiet(kind == 1 ? pos[b] : neg[b], T.I);
+  int32_t *last = kind == 0 ? T.lastU + row : T.lastI + row;
+  int old = t;
+  if (valid && lane == 0) {
+    old = *last;                                           // most occurrences find their row current (touched last step, or a
+    if (old < t - 1) old = atomicMax(last, t - 1);         // sibling occurrence came first): no atomic then
+  }
+  // The few rows that need a replay get the WHOLE wave (lane = element), one after the other: in the reference's visiting
+  // order a user's ~20 triplets are neighbours, so at most one of a wave's 64/G lane groups has work and a replay inside
+  // the group would run the long recurrence with G of 64 lanes (measured on C2: 112 us for the catch-up, ALU-bound).
+  const int wl = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 64 / G; ++q) {
+    const int old_q = __shfl(old, q * G, 64);
+    if (old_q >= t - 1) continue;                          // wave-uniform
+    const int row_q = __shfl(row, q * G, 64), kind_q = __shfl(kind, q * G, 64);
+    adam_replay_kind<64, false>(T, kind_q == 0, row_q, wl, old_q, t - 1, a);
+  }
+}
+
+// After the gradients of step t are staged: one lane group per occurrence claims its touched row (flag), replays what is
+// still missing up to t-1 (nothing after k_adam_catchup; rows touched only by OTHER ranks' batches in the replicated
+// multi-GPU step were not caught up), applies step t with the staged gradient, re-zeroes the staging row, last = t.
+template <int G, bool VEC>
+__device__ __forceinline__ void adam_apply_row(float *p, float *m, float *v, float *g, int n, int lane, int t, float lr_t,
+                                               const AdamLazy &a) {
+  if (VEC) {
+    for (int c = lane * 4; c < n; c += G * 4) {
+      float4 pp = ld4(p + c), mm = ld4(m + c), vv = ld4(v + c);
+      const float4 gg = ld4(g + c);
+      adam_elem(pp.x, mm.x, vv.x, gg.x, a.b1, a.b2, lr_t, a.eps); adam_elem(pp.y, mm.y, vv.y, gg.y, a.b1, a.b2, lr_t, a.eps);
+      adam_elem(pp.z, mm.z, vv.z, gg.z, a.b1, a.b2, lr_t, a.eps); adam_elem(pp.w, mm.w, vv.w, gg.w, a.b1, a.b2, lr_t, a.eps);
+      *reinterpret_cast<float4 *>(p + c) = pp; *reinterpret_cast<float4 *>(m + c) = mm; *reinterpret_cast<float4 *>(v + c) = vv;
+      *reinterpret_cast<float4 *>(g + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    for (int c = lane; c < n; c += G) {
+      float pp = p[c], mm = m[c], vv = v[c];
+      adam_elem(pp, mm, vv, g[c], a.b1, a.b2, lr_t, a.eps);
+      p[c] = pp; m[c] = mm; v[c] = vv;
+      g[c] = 0.f;
+    }
+  }
+}
+
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_adam_apply_lazy(AdamTables T, AdamLazy a, float *dGu, float *dTu, float *dGi, float *dBi,
+                                                         uint32_t *flagU, uint32_t *flagI, const int32_t *__restrict__ user,
+                                                         const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
+                                                         int64_t B, int t, float lr_t, int first_kind, int end_kind) {
+  const int64_t job = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G + (int64_t)first_kind * B;
+  const int lane = threadIdx.x % G;
+  if (job >= (int64_t)end_kind * B) return;
+  const int kind = (int)(job / B);
+  const int64_t b = job - (int64_t)kind * B;
+  const int row = kind == 0 ? clamp_quiet(user[b], T.U) : clamp_quiet(kind == 1 ? pos[b] : neg[b], T.I);
+  uint32_t *flag = kind == 0 ? flagU + row : flagI + row;
+  unsigned claimed = 0;
+  if (lane == 0) claimed = atomicExch(flag, 0u);
+  claimed = __shfl(claimed, 0, G);
+  if (!claimed) return;
+  int32_t *last = kind == 0 ? T.lastU + row : T.lastI + row;
+  const int from = *last;
+  if (from < t - 1) adam_replay_kind<G, VEC>(T, kind == 0, row, lane, from, t - 1, a);   // group-uniform; rare (see above)
+  if (kind == 0) {
+    adam_apply_row<G, VEC>(T.Gu + (size_t)row * T.k, T.mGu + (size_t)row * T.k, T.vGu + (size_t)row * T.k, dGu + (size_t)row * T.k, T.k, lane, t, lr_t, a);
+    if (T.d) adam_apply_row<G, VEC>(T.Tu + (size_t)row * T.d, T.mTu + (size_t)row * T.d, T.vTu + (size_t)row * T.d, dTu + (size_t)row * T.d, T.d, lane, t, lr_t, a);
+  } else {
+    adam_apply_row<G, VEC>(T.Gi + (size_t)row * T.k, T.mGi + (size_t)row * T.k, T.vGi + (size_t)row * T.k, dGi + (size_t)row * T.k, T.k, lane, t, lr_t, a);
+    if (lane == 0) adam_apply_row<1, false>(T.Bi + row, T.mBi + row, T.vBi + row, dBi + row, 1, 0, t, lr_t, a);
+  }
+  if (lane == 0) *last = t;                                // (every lane has read `from` before: same wave, in order)
+}
+
+// Full catch-up (bprx_sync_adam; before predict_all / a snapshot; before the lr ring wraps): every row to step t.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_adam_sync(AdamTables T, AdamLazy a, int t) {
+  const int lane = threadIdx.x % G;
+  const int64_t ngroups = (int64_t)gridDim.x * 256 / G;
+  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G; r < (int64_t)T.U + T.I; r += ngroups) {
+    const bool usr = r < T.U;
+    const int row = usr ? (int)r : (int)(r - T.U);
+    int32_t *last = usr ? T.lastU + row : T.lastI + row;
+    const int old = *last;
+    if (old >= t) continue;
+    adam_replay_kind<G, VEC>(T, usr, row, lane, old, t, a);
+    if (lane == 0) *last = t;
+  }
+}
+
+__global__ void k_fill_i32(int32_t *p, size_t n, int32_t v) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = v;
 }
 
 __global__ void k_clear_flags(uint32_t *f, size_t n) {
@@ -689,11 +916,16 @@ __global__ __launch_bounds__(256) void k_score_block(SparseArgs a, int u0, int u
 // one lane group each (led by the occurrences of rank 0, SEG_CAP, 2 SEG_CAP, ...): bounded serial walk per group; the
 // chunks' partial sums meet in the item's staging rows and the chunk that finishes last completes the item.
 // ------------------------------------------------------------------------------------------------------------
-template <int G, bool ADAM>
+// ADAM: 0 = sgd (items finished in place), 1 = adam_tf23 with whole-table sweeps (the gradient goes to the staging tables),
+//       2 = lazy-exact adam_tf23: the item's Adam step is taken right here from the registers that hold its row and its
+//           gradient (the row is current: k_adam_catchup ran) -- no staging round trip, no apply pass for the items.
+struct AdamFuse { float *mGi, *vGi, *mBi, *vBi; int32_t *lastI; float b1, b2, eps; int t; };
+
+template <int G, int ADAM>
 __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
                                                   float *__restrict__ Wf, uint16_t *__restrict__ Wb,
                                                   const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B,
-                                                  float lr) {
+                                                  float lr, AdamFuse af) {
   const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   if (job >= 2 * B) return;
@@ -775,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
     }
     if (lane == 0) { gb = atomicAdd(a.dBi + item, 0.f); if (d) wl = atomicAdd(a.W + ow + d, 0.f); }
     if (lane == 0) a.hot_done[item] = 0;
-    if (!ADAM) {                                                      // staging back to zero (adam: it IS the gradient)
+    if (ADAM == 0) {                                                  // staging back to zero (adam sweeps: it IS the gradient)
       if (hk) *reinterpret_cast<float4 *>(a.dGi + og) = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lane == 0) a.dBi[item] = 0.f;
     }
@@ -786,13 +1018,32 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
     // fall through: finish the item from the totals
     if (hk && !ADAM) *reinterpret_cast<float4 *>(Gi + og) = make_float4(q.x - lr * gr.x, q.y - lr * gr.y, q.z - lr * gr.z, q.w - lr * gr.w);
     if (lane == 0 && !ADAM) Bi[item] = pb - lr * gb;
+    if (lane == 0 && ADAM == 1) a.flagI[item] = 1u;       // hot item, adam sweeps: the totals stay in the staging rows
+    if (ADAM == 2) {                                      // hot item, lazy adam: staging back to zero, step taken below
+      if (hk) *reinterpret_cast<float4 *>(a.dGi + og) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane == 0) a.dBi[item] = 0.f;
+    }
   } else {
     if (hk) {
-      if (ADAM) *reinterpret_cast<float4 *>(a.dGi + og) = gr;
-      else *reinterpret_cast<float4 *>(Gi + og) = make_float4(q.x - lr * gr.x, q.y - lr * gr.y, q.z - lr * gr.z, q.w - lr * gr.w);
+      if (ADAM == 1) *reinterpret_cast<float4 *>(a.dGi + og) = gr;
+      else if (ADAM == 0) *reinterpret_cast<float4 *>(Gi + og) = make_float4(q.x - lr * gr.x, q.y - lr * gr.y, q.z - lr * gr.z, q.w - lr * gr.w);
     }
     if (lane == 0) {
-      if (ADAM) a.dBi[item] = gb; else Bi[item] = pb - lr * gb;
+      if (ADAM == 1) { a.dBi[item] = gb; a.flagI[item] = 1u; } else if (ADAM == 0) Bi[item] = pb - lr * gb;
+    }
+  }
+  if (ADAM == 2) {                                        // one Adam step (lr = lr_t) on the item's rows, here and now
+    if (hk) {
+      float4 mm = ld4(af.mGi + og), vv = ld4(af.vGi + og);
+      adam_elem(q.x, mm.x, vv.x, gr.x, af.b1, af.b2, lr, af.eps); adam_elem(q.y, mm.y, vv.y, gr.y, af.b1, af.b2, lr, af.eps);
+      adam_elem(q.z, mm.z, vv.z, gr.z, af.b1, af.b2, lr, af.eps); adam_elem(q.w, mm.w, vv.w, gr.w, af.b1, af.b2, lr, af.eps);
+      *reinterpret_cast<float4 *>(Gi + og) = q; *reinterpret_cast<float4 *>(af.mGi + og) = mm; *reinterpret_cast<float4 *>(af.vGi + og) = vv;
+    }
+    if (lane == 0) {
+      float pbv = pb, mb = af.mBi[item], vb = af.vBi[item];
+      adam_elem(pbv, mb, vb, gb, af.b1, af.b2, lr, af.eps);
+      Bi[item] = pbv; af.mBi[item] = mb; af.vBi[item] = vb;
+      af.lastI[item] = af.t;
     }
   }
   if (d) {
@@ -834,6 +1085,15 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   }
   a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
   return a;
+}
+
+AdamTables make_adam_tables(bprx_handle *h) {
+  AdamTables T;
+  T.Gu = h->t.Gu; T.mGu = h->t.m_Gu; T.vGu = h->t.v_Gu; T.Tu = h->t.Tu; T.mTu = h->t.m_Tu; T.vTu = h->t.v_Tu;
+  T.Gi = h->t.Gi; T.mGi = h->t.m_Gi; T.vGi = h->t.v_Gi; T.Bi = h->t.Bi; T.mBi = h->t.m_Bi; T.vBi = h->t.v_Bi;
+  T.lastU = h->lastU; T.lastI = h->lastI;
+  T.U = h->cfg.num_users; T.I = h->cfg.num_items; T.k = h->cfg.embed_k; T.d = h->cfg.embed_d;
+  return T;
 }
 
 // group width: smallest power of two G in [8,64] with G*4 >= max(k,d)
@@ -950,6 +1210,53 @@ __global__ __launch_bounds__(256) void k_apply_user_msg(const float *__restrict_
   for (int c = lane; c < d; c += G) pt[c] += scale * it[c];
 }
 
+// adam_tf23 in the replicated-user step: a user's gradient is the SUM over the ranks' rows (a user may sit in several
+// ranks' batches), so the rows are first added into the zeroed staging tables rank by rank (ids are distinct within a
+// message: plain read-modify-write, the same additions in the same order on every replica) ...
+__global__ __launch_bounds__(256) void k_accum_user_msg(const float *__restrict__ msg, int cap, int U, int k, int d,
+                                                        float *__restrict__ dGu, float *__restrict__ dTu,
+                                                        uint32_t *__restrict__ flagU) {
+  constexpr int G = 16;
+  const int slot = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) / G), lane = threadIdx.x % G;
+  int cnt = reinterpret_cast<const int32_t *>(msg)[0];
+  cnt = cnt < cap ? cnt : cap;
+  if (slot >= cnt) return;
+  const int u = reinterpret_cast<const int32_t *>(msg)[1 + slot];
+  if ((unsigned)u >= (unsigned)U) return;
+  const float *ig = msg + 1 + cap + (size_t)slot * k, *it = msg + 1 + cap + (size_t)cap * k + (size_t)slot * d;
+  float *pg = dGu + (size_t)u * k, *pt = d ? dTu + (size_t)u * d : nullptr;
+  for (int c = lane; c < k; c += G) pg[c] += ig[c];
+  for (int c = lane; c < d; c += G) pt[c] += it[c];
+  if (lane == 0) flagU[u] = 1u;
+}
+
+// ... and then every touched user takes ONE lazy-exact Adam step (replay of what the row missed, then step t): one lane
+// group per (rank, slot), the first to claim the user's flag does it.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_adam_apply_msg_users(AdamTables T, AdamLazy a, const float *__restrict__ msgs, int nranks,
+                                                              size_t stride, int cap, float *dGu, float *dTu, uint32_t *flagU,
+                                                              int t, float lr_t) {
+  const int64_t job = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (job >= (int64_t)nranks * cap) return;
+  const int r = (int)(job / cap), slot = (int)(job - (int64_t)r * cap);
+  const float *msg = msgs + (size_t)r * stride;
+  int cnt = reinterpret_cast<const int32_t *>(msg)[0];
+  cnt = cnt < cap ? cnt : cap;
+  if (slot >= cnt) return;
+  const int row = reinterpret_cast<const int32_t *>(msg)[1 + slot];
+  if ((unsigned)row >= (unsigned)T.U) return;
+  unsigned claimed = 0;
+  if (lane == 0) claimed = atomicExch(flagU + row, 0u);
+  claimed = __shfl(claimed, 0, G);
+  if (!claimed) return;
+  const int from = T.lastU[row];
+  if (from < t - 1) adam_replay_kind<G, VEC>(T, true, row, lane, from, t - 1, a);
+  adam_apply_row<G, VEC>(T.Gu + (size_t)row * T.k, T.mGu + (size_t)row * T.k, T.vGu + (size_t)row * T.k, dGu + (size_t)row * T.k, T.k, lane, t, lr_t, a);
+  if (T.d) adam_apply_row<G, VEC>(T.Tu + (size_t)row * T.d, T.mTu + (size_t)row * T.d, T.vTu + (size_t)row * T.d, dTu + (size_t)row * T.d, T.d, lane, t, lr_t, a);
+  if (lane == 0) T.lastU[row] = t;
+}
+
 // dEp = sum over ranks (fixed order) of the dense parts of their messages
 __global__ __launch_bounds__(256) void k_sum_dense_msgs(const float *__restrict__ msgs, int nranks, size_t stride, size_t off,
                                                         size_t n, float *__restrict__ dEp) {
@@ -965,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_sum_dense_msgs(const float *__restrict_
 extern "C" int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap) {
   if (!h || cap <= 0) return -1;
   const int64_t k = h->cfg.embed_k, d = h->cfg.embed_d, D = h->cfg.feat_dim;
-  return 1 + cap + cap * (k + d) + D * d + D;
+  return 1 + cap + cap * (k + d) + ((h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : D * d + D);
 }
 
 extern "C" int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream) {
@@ -977,7 +1284,7 @@ extern "C" int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B
   hipLaunchKernelGGL(k_pack_user_msg, dim3((unsigned)((B * 16 + 255) / 256)), dim3(256), 0, s, user, B, h->cfg.num_users, k, d,
                      (int)cap, h->flagU, h->dGu, h->dTu, msg, h->errflag);
   BPRX_LAUNCH_CHECK(h, "k_pack_user_msg");
-  const size_t nd = (size_t)h->cfg.feat_dim * (d + 1);
+  const size_t nd = (h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : (size_t)h->cfg.feat_dim * (d + 1);
   if (nd) BPRX_HIP(h, hipMemcpyAsync(msg + 1 + cap + cap * (int64_t)(k + d), h->dEp, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
   return BPRX_OK;
 }
@@ -988,10 +1295,24 @@ extern "C" int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t n
   hipStream_t s = (hipStream_t)stream;
   const int k = h->cfg.embed_k, d = h->cfg.embed_d;
   const size_t stride = (size_t)bprx_user_msg_floats(h, cap);
+  if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
+    // sum the ranks' rows per user (rank order), then one lazy-exact Adam step per touched user (`scale` is sgd's -lr)
+    for (int r = 0; r < nranks; ++r)
+      hipLaunchKernelGGL(k_accum_user_msg, dim3((unsigned)((cap * 16 + 255) / 256)), dim3(256), 0, s, msgs + (size_t)r * stride,
+                         (int)cap, h->cfg.num_users, k, d, h->dGu, h->dTu, h->flagU);
+    const float tt = (float)h->adam_t;
+    const float lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, tt)) / (1.0f - powf(h->cfg.beta1, tt));
+    const bool vec = vec_ok(h);
+    const int G = pick_group(k, d, vec);
+    const AdamTables T = make_adam_tables(h);
+    const AdamLazy al = {h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->lr_hist};
+    DISPATCH_G(G, vec, k_adam_apply_msg_users, grid_for((int64_t)nranks * cap, G), s, T, al, msgs, (int)nranks, stride, (int)cap,
+               h->dGu, h->dTu, h->flagU, (int)h->adam_t, lr_t);
+  } else
   for (int r = 0; r < nranks; ++r)                                             // rank order: identical on every replica
     hipLaunchKernelGGL(k_apply_user_msg, dim3((unsigned)((cap * 16 + 255) / 256)), dim3(256), 0, s, msgs + (size_t)r * stride,
                        (int)cap, h->cfg.num_users, k, d, h->t.Gu, h->t.Tu, scale);
-  const size_t nd = (size_t)h->cfg.feat_dim * (d + 1);
+  const size_t nd = (h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : (size_t)h->cfg.feat_dim * (d + 1);
   if (nd) {
     unsigned blocks = (unsigned)((nd + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1059,17 +1380,19 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
   if (!h->item_mode) return BPRX_OK;
   SparseArgs a = make_args(h, nullptr);
   const int G = pick_group(a.k, a.d, true);
-  const bool adam = h->cfg.optimizer == BPRX_OPT_ADAM_TF23;
+  const int adam = h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? (h->adam_lazy ? 2 : 1) : 0;
   const bool bf = h->cfg.feat_dtype != BPRX_F_FP32;     // bf16 W image (bf16 and fp8 features)
   float *Wf = a.d && !bf ? h->W : nullptr;
   uint16_t *Wb = a.d && bf ? (uint16_t *)h->Wb : nullptr;
+  const AdamFuse af = {h->t.m_Gi, h->t.v_Gi, h->t.m_Bi, h->t.v_Bi, h->lastI, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, (int)h->adam_t};
   BprxProfScope ps(h, BPRX_PHASE_ITEM_SEG, s);
   // (the bf16 image was re-zeroed by k_row_count: rows of untouched items stay zero)
   const dim3 grid = grid_for(2 * B, G);
 #define LAUNCH_SEG(GG)                                                                                                   \
   do {                                                                                                                   \
-    if (adam) hipLaunchKernelGGL((k_item_seg<GG, true>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t); \
-    else hipLaunchKernelGGL((k_item_seg<GG, false>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t);     \
+    if (adam == 2) hipLaunchKernelGGL((k_item_seg<GG, 2>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t, af); \
+    else if (adam) hipLaunchKernelGGL((k_item_seg<GG, 1>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t, af); \
+    else hipLaunchKernelGGL((k_item_seg<GG, 0>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t, af);          \
   } while (0)
   switch (G) {
     case 8: LAUNCH_SEG(8); break;
@@ -1100,6 +1423,19 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     return BPRX_OK;
   }
   const float b1 = h->cfg.beta1, b2 = h->cfg.beta2, eps = h->cfg.epsilon;
+  if (h->adam_lazy) {                                    // touched rows only (claim per occurrence); everything else is replayed later
+    const bool vec = vec_ok(h);
+    const int G = pick_group(a.k, a.d, vec);
+    const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;      // replicated multi-GPU: users via bprx_apply_user_msgs
+    const int ek = h->item_mode ? 1 : 3;                                     // segments: k_item_seg took the items' steps
+    const AdamTables T = make_adam_tables(h);
+    const AdamLazy al = {b1, b2, eps, h->lr_hist};
+    if (ek > fk)
+      DISPATCH_G(G, vec, k_adam_apply_lazy, grid_for((int64_t)(ek - fk) * B, G), s, T, al, h->dGu, h->dTu, h->dGi, h->dBi, h->flagU,
+                 h->flagI, u, i, j, B, (int)h->adam_t, lr_t, fk, ek);
+    BPRX_LAUNCH_CHECK(h, "k_adam_apply_lazy");
+    return BPRX_OK;
+  }
   auto sweep = [&](float *p, float *m, float *v, float *g, size_t n) {
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1115,6 +1451,48 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
   BPRX_LAUNCH_CHECK(h, "k_adam_sparse");
   return BPRX_OK;
 }
+
+// ---- lazy-exact adam_tf23: catch-up before the forward pass, full catch-up on demand ----
+int bprx_launch_adam_catchup(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t,
+                             hipStream_t s) {
+  const bool vec = vec_ok(h);
+  const int G = pick_group(h->cfg.embed_k, h->cfg.embed_d, vec);
+  const AdamTables T = make_adam_tables(h);
+  const AdamLazy al = {h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->lr_hist};
+  BprxProfScope ps(h, BPRX_PHASE_ADAM_CATCHUP, s);
+  DISPATCH_G(G, vec, k_adam_catchup, grid_for(3 * B, G), s, T, al, u, i, j, B, (int)h->adam_t, lr_t, h->lr_hist);
+  BPRX_LAUNCH_CHECK(h, "k_adam_catchup");
+  return BPRX_OK;
+}
+
+// every row to step `t` (<= adam_t); no-op when nothing is pending
+int bprx_launch_adam_sync(bprx_handle *h, int64_t t, hipStream_t s) {
+  if (!h->adam_lazy || h->adam_synced >= t) return BPRX_OK;
+  const bool vec = vec_ok(h);
+  const int G = pick_group(h->cfg.embed_k, h->cfg.embed_d, vec);
+  const AdamTables T = make_adam_tables(h);
+  const AdamLazy al = {h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->lr_hist};
+  const int64_t rows = (int64_t)T.U + T.I;
+  int64_t blocks = (rows * G + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  DISPATCH_G(G, vec, k_adam_sync, dim3((unsigned)blocks), s, T, al, (int)t);
+  BPRX_LAUNCH_CHECK(h, "k_adam_sync");
+  h->adam_synced = t;
+  return BPRX_OK;
+}
+
+// every row counts as current at step t (bind, resume, outside writes): nothing to replay
+int bprx_launch_adam_reset(bprx_handle *h, int64_t t, hipStream_t s) {
+  if (!h->adam_lazy) return BPRX_OK;
+  hipLaunchKernelGGL(k_fill_i32, dim3(512), dim3(256), 0, s, h->lastU, (size_t)h->cfg.num_users, (int32_t)t);
+  hipLaunchKernelGGL(k_fill_i32, dim3(512), dim3(256), 0, s, h->lastI, (size_t)h->cfg.num_items, (int32_t)t);
+  BPRX_LAUNCH_CHECK(h, "k_fill_i32");
+  if (s == nullptr) BPRX_HIP(h, hipStreamSynchronize(nullptr));   // control-path callers (bind, resume, tables_dirty) pass no
+  h->adam_synced = t;                                             // stream: complete before work on any other stream
+  return BPRX_OK;
+}
+
+int bprx_adam_hist(void) { return ADAM_HIST; }
 
 int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   const int D = h->cfg.feat_dim;

@@ -148,18 +148,26 @@ class ReplicatedUserVBPR:
     No data-dependent split sizes, hence no host synchronisation and no all-to-all; the message holds `user_cap` distinct
     users per batch (epoch-walk batches of B triplets touch about B / positives-per-user of them; more than user_cap is
     reported by sync_check()).  The global step equals the single-GPU batch-synchronous step on the concatenation of all
-    ranks' batches (tests/test_gpu_dist.py).  sgd only."""
+    ranks' batches (tests/test_gpu_dist.py)."""
 
     def __init__(self, rank, world, Gu, Tu, Gi_shard, Bi_shard, F_shard, E, Bp, lr, reg, max_batch, user_cap=None,
-                 feat_dtype="bf16", group=None, device=None):
+                 feat_dtype="bf16", group=None, device=None, optimizer="sgd", dense_reduce="gather"):
+        """optimizer: 'sgd' | 'adam_tf23' (lazy-exact: every replica sums the ranks' rows per user in rank order and takes
+        the same Adam step, so the replicas stay bit-identical).
+        dense_reduce: 'gather' = dE|dBp travels inside the message and is summed in rank order (bit-identical replicas by
+        construction); 'allreduce' = a separate RCCL all-reduce(sum) of the dense gradient, the form north_star names --
+        (N-1)/N instead of N-1 message-sized transfers per rank for the dense part, one more collective per step."""
         from .engine import Engine
         self.rank, self.world, self.group, self.lr = rank, world, group, lr
+        self.dense_reduce = dense_reduce
         k, d = Gu.shape[1], Tu.shape[1]
         self.eng = Engine(model="vbpr", num_users=Gu.shape[0], num_items=Gi_shard.shape[0], embed_k=k, embed_d=d,
-                          feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer="sgd", lr=lr, reg=reg,
-                          max_batch=max_batch, device=device, export_user_grad=True)
+                          feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer=optimizer, lr=lr, reg=reg,
+                          max_batch=max_batch, device=device, export_user_grad=True,
+                          dense_allreduce=(dense_reduce == "allreduce"))
         self.eng.bind(Gu=Gu, Gi=Gi_shard, Bi=Bi_shard, Tu=Tu, F=F_shard, E=E, Bp=Bp)
         dev = self.eng.device
+        self.dense = self.eng.dense_grad() if dense_reduce == "allreduce" else None
         self.cap = int(user_cap if user_cap is not None else max_batch)
         n = self.eng.user_msg_floats(self.cap)
         self.msg = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -177,6 +185,13 @@ class ReplicatedUserVBPR:
     def step(self, u_global, i_local, j_local, want_loss=False):
         self.eng.step_begin(u_global, i_local, j_local)
         self.eng.pack_user_msg(u_global, self.cap, self.msg)
+        if self.dense is not None and self.world > 1:                  # dense_reduce == 'allreduce': RCCL sum of dE|dBp
+            if self.host_staged:
+                h = self.dense.cpu()
+                dist.all_reduce(h, group=self.group)
+                self.dense.copy_(h)
+            else:
+                dist.all_reduce(self.dense, group=self.group)
         if self.world == 1 and not dist.is_initialized():
             self.msgs.copy_(self.msg)
         elif self.host_staged:

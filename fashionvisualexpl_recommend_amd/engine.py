@@ -34,7 +34,8 @@ def as_index(x, device):
 class Engine:
     def __init__(self, model, num_users, num_items, embed_k, embed_d=0, feat_dim=0, feat_dtype="fp32",
                  optimizer="adam_tf23", lr=1e-3, reg=0.0, max_batch=256, device=None,
-                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False, export_item_grad=False, feat_scale=448.0):
+                 beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False, export_item_grad=False, feat_scale=448.0,
+                 dense_allreduce=False):
         if not torch.cuda.is_available():
             raise RuntimeError("fashionvisualexpl_recommend_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _ffi.lib()
@@ -49,12 +50,28 @@ class Engine:
                           _ffi.FEAT_DTYPE[feat_dtype], _ffi.OPTIMIZER[optimizer], self.device.index, self.max_batch,
                           lr, reg, beta1, beta2, epsilon,
                           (_ffi.FLAG_EXPORT_USER_GRAD if export_user_grad else 0) |
-                          (_ffi.FLAG_EXPORT_ITEM_GRAD if export_item_grad else 0), self.feat_scale)
+                          (_ffi.FLAG_EXPORT_ITEM_GRAD if export_item_grad else 0) |
+                          (_ffi.FLAG_DENSE_ALLREDUCE if dense_allreduce else 0), self.feat_scale)
         h = C.c_void_p()
         _ffi.check(None, self.lib.bprx_create(C.byref(cfg), C.byref(h)))
         self.h = h
-        self.t = {}
+        self._t = {}
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    @property
+    def t(self):
+        """The bound tensors.  adam_tf23 is lazy-exact inside the library: reading the tensors from outside first brings
+        every row up to date (bprx_sync_adam; a host call that returns at once when nothing is pending)."""
+        if self.optimizer == "adam_tf23" and getattr(self, "h", None) and self._t:
+            self.sync_adam()
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
+
+    def sync_adam(self):
+        _ffi.check(self.h, self.lib.bprx_sync_adam(self.h, _stream()))
 
     def close(self):
         if getattr(self, "h", None):

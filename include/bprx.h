@@ -78,7 +78,11 @@ typedef struct {
    their owner ranks (row b = the user row of triplet b); the step leaves their summed gradients in the buffers of
    bprx_user_grad() instead of applying them, and the caller routes those rows back to the owners
    (bprx_scatter_add with scale = -lr) and clears them with bprx_clear_user_grad(). */
-enum { BPRX_FLAG_EXPORT_USER_GRAD = 1, BPRX_FLAG_EXPORT_ITEM_GRAD = 2 };
+enum { BPRX_FLAG_EXPORT_USER_GRAD = 1, BPRX_FLAG_EXPORT_ITEM_GRAD = 2, BPRX_FLAG_DENSE_ALLREDUCE = 4 };
+/* BPRX_FLAG_DENSE_ALLREDUCE (with BPRX_FLAG_EXPORT_USER_GRAD, replicated-user step): the per-rank message carries NO dense
+   part; the caller all-reduces (sum, RCCL) the buffer of bprx_dense_grad() between bprx_pack_user_msg and bprx_step_end --
+   the "RCCL all-reduce on E / beta'" form of SURVEY 8(e).  Without it dE|dBp rides in the all-gathered message and is summed
+   in rank order (bit-identical replicas whatever the collective's reduction order). */
 /* BPRX_FLAG_EXPORT_ITEM_GRAD (user-sharded multi-GPU BPRMF, sgd only): the mirror image -- the bound Gi/Bi are per-step
    STAGING rows fetched from the item owners (row b = the positive item row of triplet b, row B+b its negative item row);
    their gradients are left in the buffers of bprx_item_grad() and cleared with bprx_clear_item_grad(). */
@@ -116,6 +120,13 @@ BPRX_API int bprx_bind_tables(bprx_handle *h, const bprx_tables *t);
 BPRX_API int bprx_tables_dirty(bprx_handle *h);
 BPRX_API int bprx_set_hyper(bprx_handle *h, float lr, float reg);           /* train_rec.py:69 (args.reg = reg) */
 BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations);         /* optimizer.iterations (resume) */
+/* adam_tf23 is implemented LAZILY but exactly: TF-2.3's Adam moves every row of every table every step (non-lazy sparse
+   apply, BPRMF.py:123 / VBPR.py:142); here a row that received no gradient is brought up to date -- by replaying the
+   skipped steps with the arithmetic of the whole-table sweep, bit for bit -- when it is next read.  The library does that
+   itself wherever IT reads the tables (steps, bprx_score_pairs, bprx_score_block); a caller that reads the bound tensors
+   directly (snapshot, inspection) calls bprx_sync_adam first: afterwards every row holds what TF's tables would hold after
+   optimizer.iterations steps.  No-op for sgd, or when nothing is pending.  (BPRX_ADAM_LAZY=0: the sweeps, for A/B.) */
+BPRX_API int bprx_sync_adam(bprx_handle *h, void *stream);
 BPRX_API int64_t bprx_get_adam_step(const bprx_handle *h);
 
 /* Model.call((user,item)) -> xui        BPRMF.py:55-76 / VBPR.py:59-86.   x: fp32 [B] */
@@ -176,7 +187,7 @@ BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out
 enum {
   BPRX_PHASE_CAST_ET = 0, BPRX_PHASE_PROJ_FWD = 1, BPRX_PHASE_TRIPLET = 2, BPRX_PHASE_PROJ_BWD = 3,
   BPRX_PHASE_REDUCE = 4, BPRX_PHASE_APPLY = 5, BPRX_PHASE_DENSE = 6, BPRX_PHASE_LOSS = 7, BPRX_PHASE_ITEM_SEG = 8,
-  BPRX_PHASE_SEG_ALLOC = 9, BPRX_PHASE_ROW_COUNT = 10, BPRX_PHASE_COUNT = 11
+  BPRX_PHASE_SEG_ALLOC = 9, BPRX_PHASE_ROW_COUNT = 10, BPRX_PHASE_ADAM_CATCHUP = 11, BPRX_PHASE_COUNT = 12
 };
 BPRX_API int bprx_profile_enable(bprx_handle *h, int on);
 BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);

@@ -127,7 +127,7 @@ def test_user_sharded_bprmf_two_ranks_match_oracle():
     mp.spawn(_worker_bprmf, args=(2, _free_port()), nprocs=2, join=True)
 
 
-def _worker_replicated(rank, world, port, dtype):
+def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -135,7 +135,7 @@ def _worker_replicated(rank, world, port, dtype):
         from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR
         from oracle import oracle as orc
         torch.cuda.set_device(0)
-        U, I, k, d, D, B, lr, reg = 45, 64, 8, 20, 256, 96, 0.05, 1e-3
+        U, I, k, d, D, B, lr, reg = 45, 64, 8, 20, 256, 96, (0.05 if opt == "sgd" else 0.01), 1e-3
         ish = I // world
         rs = np.random.RandomState(1)
         F = synth.make_features(I, D, seed=1)
@@ -148,22 +148,27 @@ def _worker_replicated(rank, world, port, dtype):
         it = slice(rank * ish, (rank + 1) * ish)
         c = lambda a: torch.as_tensor(a.copy())
         m = ReplicatedUserVBPR(rank, world, c(t["Gu"]), c(t["Tu"]), c(t["Gi"][it]), c(t["Bi"][it]), c(t["F"][it]), c(t["E"]),
-                               c(t["Bp"]), lr, reg, max_batch=B, user_cap=U, feat_dtype=dtype, device=0)
+                               c(t["Bp"]), lr, reg, max_batch=B, user_cap=U, feat_dtype=dtype, device=0, optimizer=opt,
+                               dense_reduce=dense_reduce)
         o = orc.OracleModel(**t, quant=1 if dtype == "bf16" else 0)
-        for step in range(3):
+        for step in range(4 if opt != "sgd" else 3):
             batches = []
             for r in range(world):
                 br = np.random.RandomState(300 + step * world + r)
                 nb = B - 10 * r                           # ragged
                 batches.append((br.randint(U, size=nb).astype(np.int32), br.randint(ish, size=nb).astype(np.int32),
                                 br.randint(ish, size=nb).astype(np.int32)))
+            if opt != "sgd" and step >= 2:                # adam: some users only in the OTHER rank's batch, some in nobody's
+                batches = [(b[0] % (10 + 7 * r) + 20 * r, b[1], b[2]) for r, b in enumerate(batches)]
             u, i, j = batches[rank]
             dev = lambda a: torch.as_tensor(a, device="cuda")
             m.step(dev(u), dev(i), dev(j))
             o.step(np.concatenate([b[0] for b in batches]), np.concatenate([b[1] + r * ish for r, b in enumerate(batches)]),
-                   np.concatenate([b[2] + r * ish for r, b in enumerate(batches)]), "sgd", lr, reg)
+                   np.concatenate([b[2] + r * ish for r, b in enumerate(batches)]), opt, lr, reg)
         m.eng.sync_check()
         rt, at = (2e-5, 2e-6) if dtype == "fp32" else (2e-3, 1e-4)
+        if opt != "sgd":
+            at = max(at, 2e-3 * lr)                        # see test_gpu_parity.test_bprmf_steps_match_oracle
         chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=rt, atol=at, err_msg=n)
         chk(m.Gu, o.Gu, "Gu (replicated)")
         chk(m.Tu, o.Tu, "Tu (replicated)")
@@ -187,6 +192,17 @@ def _worker_replicated(rank, world, port, dtype):
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_replicated_user_vbpr_two_ranks_match_oracle(dtype):
     mp.spawn(_worker_replicated, args=(2, _free_port(), dtype), nprocs=2, join=True)
+
+
+def test_replicated_user_vbpr_two_ranks_adam_tf23_match_oracle():
+    """The reference's optimizer (Adam, VBPR.py:56,142) through the replicated-user multi-GPU step: lazy-exact rows, users
+    summed over the ranks' messages in rank order, replicas bit-identical."""
+    mp.spawn(_worker_replicated, args=(2, _free_port(), "fp32", "adam_tf23"), nprocs=2, join=True)
+
+
+def test_replicated_user_vbpr_dense_allreduce_form():
+    """dense_reduce='allreduce': dE|dBp leaves the message and is summed by a collective all-reduce (north_star's form)."""
+    mp.spawn(_worker_replicated, args=(2, _free_port(), "fp32", "sgd", "allreduce"), nprocs=2, join=True)
 
 
 def test_replicated_user_message_overflow_is_reported():
