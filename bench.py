@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--dist-mode", default="replicated", choices=["replicated", "a2a"],
                     help="N > 1, VBPR: replicated = user tables on every rank, one all-gather per step (default); "
                          "a2a = user tables range-partitioned, rows fetched / gradients returned by all-to-all")
+    ap.add_argument("--dense-reduce", default="gather", choices=["gather", "allreduce"],
+                    help="N > 1, replicated mode: dE|dBp summed in rank order inside the all-gathered message (default: "
+                         "bit-identical replicas, ONE collective per step) or by a separate RCCL all-reduce (north_star's "
+                         "form: 2(N-1)/N instead of N-1 dense-gradient transfers per rank, two collectives per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-overlap", action="store_true",
                     help="draw each batch one step ahead on a side stream (measured on C2: 0.287 vs 0.280 ms/step without "
@@ -168,8 +172,8 @@ def main():
                 tables[n].copy_(hcopy)
             else:
                 dist.broadcast(tables[n], src=0)
-        if args.optimizer != "sgd":
-            raise SystemExit("multi-GPU bench supports --optimizer sgd")
+        if args.optimizer != "sgd" and args.dist_mode != "replicated":
+            raise SystemExit("multi-GPU bench: --optimizer adam_tf23 needs --dist-mode replicated")
         if args.dist_mode == "replicated":
             # users replicated on every rank (identical initial values: one generator seed for all ranks), items / F
             # sharded; ONE fixed-size all-gather per step (dist.ReplicatedUserVBPR)
@@ -181,7 +185,7 @@ def main():
             cap = B if args.sampler != "epoch" else B // args.pos_per_user + 256
             sharded = ReplicatedUserVBPR(rank, world, Gu_all, Tu_all, tables["Gi"], tables["Bi"], tables["F"], tables["E"],
                                          tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B, user_cap=cap, feat_dtype=w["dtype"],
-                                         device=local_rank)
+                                         device=local_rank, optimizer=args.optimizer, dense_reduce=args.dense_reduce)
         else:
             from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
             sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
@@ -370,8 +374,9 @@ def main():
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
                                       w["dtype"], B, args.optimizer),
                        "global_batch": B * world, "parallelism": "single" if (world == 1 and sharded is None) else
-                       ((("item-shard x%d, users replicated: one all-gather per step (distinct users' gradient rows + "
-                          "dE|dBp), local negatives" % world) if args.dist_mode == "replicated" else
+                       ((("item-shard x%d, users replicated: one all-gather per step (distinct users' gradient rows%s), "
+                          "local negatives" % (world, " + dE|dBp" if args.dense_reduce == "gather" else
+                                               "; dE|dBp by a separate RCCL all-reduce")) if args.dist_mode == "replicated" else
                          ("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world))
                         if w["model"] == "vbpr" else ("user-shard x%d: all-to-all item rows, no all-reduce" % world)),
                        "sampler": (("device philox, uniform positive + rejection negative" if args.sampler == "philox" else

@@ -79,6 +79,68 @@ class UserRowExchange:
         parts = list(torch.split(out, widths, dim=1))
         return (parts, work) if async_op else parts
 
+    # ---- fixed-capacity form: no data-dependent split sizes, hence NO host synchronisation ---------------------------
+    # Every rank sends exactly `cap` slots to every rank (a slot = one requested row id, -1 = empty), so the collectives
+    # take equal splits and nothing has to be read back to size them.  cap = slack x ceil(B / world) (default slack 2: the
+    # batch's users spread evenly over the owners up to sampling noise); a bucket that overflows is reported by
+    # overflowed() -- a device flag, read when the caller next synchronises anyway -- and its surplus rows take part with
+    # zero rows / dropped gradients in that step.
+    def _a2a_equal(self, inp):
+        out = torch.empty_like(inp)
+        if self.host_staged and inp.is_cuda:
+            o, i = out.cpu(), inp.cpu()
+            dist.all_to_all_single(o, i, group=self.group)
+            out.copy_(o)
+            return out
+        dist.all_to_all_single(out, inp.contiguous(), group=self.group)
+        return out
+
+    def plan_fixed(self, u_global, cap):
+        """Returns (order, slot, valid, recv_idx): `order` sorts the batch by owner; sorted entry p sits in send slot slot[p]
+        (owner * cap + position inside the owner's bucket) when valid[p]; recv_idx [world*cap] are the shard-local row ids
+        the other ranks ask this rank for (-1 = empty slot)."""
+        dev = u_global.device
+        owner = torch.div(u_global, self.ush, rounding_mode="floor").to(torch.int64)
+        order = torch.argsort(owner, stable=True)
+        so = owner[order]
+        counts = torch.bincount(owner, minlength=self.world)
+        start = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(u_global.numel(), device=dev) - start[so]
+        valid = pos < cap
+        slot = so * cap + pos
+        local = (u_global[order] - so * self.ush).to(torch.int32)
+        send = torch.full((self.world * cap,), -1, dtype=torch.int32, device=dev)
+        send[slot[valid]] = local[valid]
+        flag = (counts > cap).any()
+        self._overflow = flag if getattr(self, "_overflow", None) is None else (self._overflow | flag)
+        return order, slot, valid, self._a2a_equal(send)
+
+    def overflowed(self):
+        """True if any bucket of any plan_fixed() since the last call overflowed (synchronises)."""
+        f = bool(self._overflow.item()) if getattr(self, "_overflow", None) is not None else False
+        self._overflow = None
+        return f
+
+    def fetch_fixed(self, shard_tables, recv_idx, slot, valid):
+        """Owners gather the requested rows (empty slots: zero rows) and send them back; returns the rows in batch-sorted
+        order, one tensor per table."""
+        ok = recv_idx >= 0
+        idx = recv_idx.clamp(min=0).long()
+        widths = [t.shape[1] for t in shard_tables]
+        packed = torch.cat([t.index_select(0, idx) for t in shard_tables], dim=1) * ok[:, None].to(shard_tables[0].dtype)
+        got = self._a2a_equal(packed)
+        rows = got.index_select(0, slot.clamp(max=got.shape[0] - 1)) * valid[:, None].to(got.dtype)
+        return list(torch.split(rows, widths, dim=1))
+
+    def give_back_fixed(self, grad_rows, slot, valid, cap):
+        """Per-row gradients (batch-sorted order) to the owners; returns the rows aligned with plan_fixed()'s recv_idx
+        (rows of empty slots are zero and carry index -1: bprx_scatter_add skips them)."""
+        widths = [g.shape[1] for g in grad_rows]
+        packed = torch.cat(list(grad_rows), dim=1) if len(grad_rows) > 1 else grad_rows[0]
+        send = torch.zeros((self.world * cap, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        send[slot[valid]] = packed[valid]
+        return list(torch.split(self._a2a_equal(send), widths, dim=1))
+
     def give_back(self, grad_rows, send_counts, recv_counts):
         """Send per-row gradients (batch-sorted order, concatenated column-wise: ONE collective) to the owners; returns
         the rows each owner received, aligned with the recv_local_idx of plan()."""
@@ -91,11 +153,15 @@ class ItemShardedVBPR:
     """Per-rank driver of the item-sharded VBPR step (see module docstring)."""
 
     def __init__(self, rank, world, users_total, Gu_shard, Tu_shard, Gi_shard, Bi_shard, F_shard, E, Bp, lr, reg,
-                 max_batch, feat_dtype="bf16", group=None, device=None):
+                 max_batch, feat_dtype="bf16", group=None, device=None, fixed_cap=True, slack=2.0):
+        """fixed_cap (default): the row exchange uses equal, fixed-capacity splits (UserRowExchange.plan_fixed): no host
+        synchronisation inside the step; False: exact data-dependent splits (one `.cpu()` of the split sizes per step)."""
         from .engine import Engine, scatter_add
         self._scatter_add = scatter_add
         self.rank, self.world, self.group = rank, world, group
         self.lr = lr
+        self.fixed_cap = fixed_cap
+        self.cap = int(min(max_batch, -(-max_batch // world) * slack + 8))
         self.x = UserRowExchange(rank, world, users_total, group)
         k, d = Gu_shard.shape[1], Tu_shard.shape[1]
         self.eng = Engine(model="vbpr", num_users=max_batch, num_items=Gi_shard.shape[0], embed_k=k, embed_d=d,
@@ -113,6 +179,8 @@ class ItemShardedVBPR:
     def step(self, u_global, i_local, j_local, want_loss=False):
         """One global batch-synchronous step; every rank calls it with its own local batch (int32 device tensors)."""
         B = u_global.numel()
+        if self.fixed_cap:
+            return self._step_fixed(u_global, i_local, j_local, want_loss)
         order, sc, rc, ridx = self.x.plan(u_global)
         (gu, tu), work = self.x.fetch([self.Gu_shard, self.Tu_shard], ridx, sc, rc, async_op=True)
         self.eng.step_project()                                   # P = F.[E|Bp] runs beside the row fetch (xGMI)
@@ -132,6 +200,33 @@ class ItemShardedVBPR:
         loss = self.eng.step_end(want_loss=want_loss)
         dG, dT = self.eng.user_grad()
         g_back, t_back = self.x.give_back([dG[:B], dT[:B]], sc, rc)
+        self.eng.clear_user_grad(B)
+        self._scatter_add(self.Gu_shard, ridx, g_back.contiguous(), -self.lr)
+        self._scatter_add(self.Tu_shard, ridx, t_back.contiguous(), -self.lr)
+        return loss
+
+
+    def _step_fixed(self, u_global, i_local, j_local, want_loss):
+        """The same global step with fixed-capacity exchanges: every tensor op and collective is enqueued without reading
+        anything back to the host."""
+        B = u_global.numel()
+        order, slot, valid, ridx = self.x.plan_fixed(u_global, self.cap)
+        self.eng.step_project()                                   # P = F.[E|Bp]: no user rows needed
+        gu, tu = self.x.fetch_fixed([self.Gu_shard, self.Tu_shard], ridx, slot, valid)
+        self.stage_Gu[:B].copy_(gu)
+        self.stage_Tu[:B].copy_(tu)
+        i_s, j_s = i_local[order].contiguous(), j_local[order].contiguous()
+        self.eng.step_begin(self.iota[:B], i_s, j_s)
+        if self.world > 1:
+            if self.x.host_staged:
+                h = self.dense.cpu()
+                dist.all_reduce(h, group=self.group)
+                self.dense.copy_(h)
+            else:
+                dist.all_reduce(self.dense, group=self.group)     # RCCL, 4*(D*d + D) bytes
+        loss = self.eng.step_end(want_loss=want_loss)
+        dG, dT = self.eng.user_grad()
+        g_back, t_back = self.x.give_back_fixed([dG[:B], dT[:B]], slot, valid, self.cap)
         self.eng.clear_user_grad(B)
         self._scatter_add(self.Gu_shard, ridx, g_back.contiguous(), -self.lr)
         self._scatter_add(self.Tu_shard, ridx, t_back.contiguous(), -self.lr)

@@ -8,6 +8,8 @@ import os
 
 from . import configs
 
+_last_model = None
+
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description="Run train of the Recommender Model.")
@@ -35,6 +37,16 @@ def parse_args(argv=None):
     parser.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp8'],
                         help='storage type of the feature table F (fp8 = OCP e4m3fn codes of f*448)')
     parser.add_argument('--init_seed', type=int, default=0)
+    parser.add_argument('--world_size', type=int, default=1,
+                        help='> 1: one process per GPU under torch.distributed.run (reads RANK / WORLD_SIZE / LOCAL_RANK)')
+    parser.add_argument('--shard', default='item', choices=['item', 'user'],
+                        help='item: VBPR, items + features range-partitioned, users replicated; user: BPRMF, users partitioned')
+    parser.add_argument('--sampler', default='ref_stream', choices=['ref_stream', 'philox'],
+                        help="ref_stream: the reference's MT19937 index stream (single GPU); philox: device epoch walk "
+                             "(always used with --world_size > 1: negatives stay GPU-local)")
+    parser.add_argument('--dense_reduce', default='gather', choices=['gather', 'allreduce'],
+                        help='multi-GPU VBPR: how the gradient of E / beta-prime is summed over the ranks (dist.py)')
+    parser.add_argument('--dist_backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL on ROCm')
     parser.add_argument('--data_root', default=None, help="overrides the reference's '../data'")
     parser.add_argument('--results_root', default=None, help="overrides the reference's '../results'")
     return parser.parse_args(argv)
@@ -48,6 +60,15 @@ def train(argv=None):
     from .models import BPRMF, VBPR
     os.makedirs(os.path.join(configs.results_dir(), args.dataset, args.rec), exist_ok=True)     # train_rec.py:52-55
     os.makedirs(os.path.join(configs.weight_dir(), args.dataset, args.rec), exist_ok=True)
+    world = int(args.world_size)
+    if world > 1:                                                                               # one process per GPU
+        import torch.distributed as dist
+        if int(os.environ.get("WORLD_SIZE", "1")) != world:
+            raise SystemExit("--world_size %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (world, world))
+        args.gpu = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("BPRX_ONE_GPU") != "1" else 0
+        torch.cuda.set_device(args.gpu)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=args.dist_backend)
     torch.cuda.set_device(args.gpu)                                                             # train_rec.py:57
     out = []
     for it, current_reg in enumerate(list(args.list_of_regs)):                                  # train_rec.py:60
@@ -60,13 +81,21 @@ def train(argv=None):
         for arg in vars(args):
             print("\t- " + str(arg) + " = " + str(getattr(args, arg)))
         print("\n")
-        if args.rec == 'bprmf':
+        if world > 1 and args.rec == 'vbpr' and args.shard == 'item':
+            from .sharded import ShardedVBPR
+            model = ShardedVBPR(data, args)
+        elif world > 1:
+            raise NotImplementedError('--world_size > 1 from this CLI: --rec vbpr --shard item (user-sharded BPRMF is driven '
+                                      'through dist.UserShardedBPRMF / bench.py --workload c3shard)')
+        elif args.rec == 'bprmf':
             model = BPRMF(data, args)
         elif args.rec == 'vbpr':
             model = VBPR(data, args)
         else:
             raise NotImplementedError('Not implemented or unknown Recommender Model.')        # train_rec.py:86
         out.append(model.train())
+        global _last_model
+        _last_model = model                                        # (tests / interactive use)
         print('END REGULARIZATION')
         print('--------------------------------------------------------------------')
     return out
