@@ -140,6 +140,9 @@ def test_vbpr_score_pairs_and_predict(k, d, D, dtype):
 
 @pytest.mark.parametrize("k,d,D,dtype,opt,reg", [(32, 20, 128, "fp32", "sgd", 1e-3), (32, 20, 128, "fp32", "adam_tf23", 1e-3),
                                                  (8, 5, 100, "fp32", "sgd", 0.0),
+                                                 # the reference's own shape and precision: 4096-d fc2 features in fp32,
+                                                 # --embed_d 20 (train_rec.py:39-43), both optimizers
+                                                 (64, 20, 4096, "fp32", "sgd", 1e-3), (64, 20, 4096, "fp32", "adam_tf23", 1e-3),
                                                  (32, 20, 128, "bf16", "sgd", 1e-3), (64, 64, 512, "bf16", "adam_tf23", 1e-3),
                                                  (16, 128, 256, "bf16", "sgd", 0.0), (16, 256, 512, "bf16", "sgd", 1e-3)])
 def test_vbpr_steps_match_oracle(k, d, D, dtype, opt, reg):
@@ -188,6 +191,7 @@ def test_vbpr_fp8_features_match_oracle(k, d, D, opt):
     rt, at = 2e-3, 1e-4
     if opt != "sgd":
         at = max(at, 2e-3 * lr)
+    used, worst = {}, {}
     for step in range(3):
         # Every step starts from IDENTICAL state (the oracle takes over the device's tables and Adam slots): [E|Bp] is
         # re-quantised each step, and an element whose fp32 value differs in the last bits between device and oracle
@@ -206,7 +210,19 @@ def test_vbpr_fp8_features_match_oracle(k, d, D, opt):
         # moves every Bp element a little): <= 3 % of the elements may miss the tolerance, by at most 0.01 * lr (sgd)
         of, oa = (1e-3, 3 * lr) if opt != "sgd" else (3e-2, 1e-2 * lr)
         for n in ("Gu", "Gi", "Bi", "Tu", "E", "Bp"):
-            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step), of, oa)
+            got, want_n = e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1)
+            _close(got, want_n, rt, at, "%s step %d" % (n, step), of, oa)
+            bad = np.abs(got - want_n) > at + rt * np.abs(want_n)
+            used[n] = max(used.get(n, 0.0), float(bad.mean()))
+            worst[n] = max(worst.get(n, 0.0), float(np.abs(got - want_n).max()))
+    # how much of the allowance the kernels actually use ("nobody has bounded it"): everything but the two
+    # tensors fed by the bf16-rounded W (E, Bp) must meet the plain tolerance with NO outliers at all
+    # (observed on MI355X, round 2: E 0 outliers in all six cases; Bp 0 - 1.8 % of its elements, worst |diff| 3.1e-4 --
+    #  a flipped bf16 code of W[t, d], the column every Bp element sums over)
+    for n in ("Gu", "Gi", "Bi", "Tu", "E"):
+        assert used[n] == 0.0, (n, used[n])
+    print("fp8 step: outlier fraction used E %.4f Bp %.4f (allowed %.4f), worst |diff| E %.2e Bp %.2e (allowed %.2e)"
+          % (used["E"], used["Bp"], of, worst["E"], worst["Bp"], oa))
     e.sync_check()
 
 
