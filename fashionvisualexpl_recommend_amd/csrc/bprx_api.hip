@@ -26,7 +26,7 @@ static void graph_drop(bprx_handle *h) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -189,6 +189,15 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
   h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;   // per side: make_args
   if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
+  if (h->fast_rows && !(cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) &&
+      !(getenv("BPRX_SHARED_LIST") && atoi(getenv("BPRX_SHARED_LIST")) == 0)) {
+    if (dalloc_zero(&h->slist, (size_t)3 * MB) != hipSuccess || dalloc_zero(&h->slist_n, (size_t)2) != hipSuccess) {
+      snprintf(g_create_err, sizeof(g_create_err), "shared-row list allocation failed");
+      free_scratch(h);
+      delete h;
+      return BPRX_E_NOMEM;
+    }
+  }
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -72,6 +72,8 @@ struct bprx_handle {
   int64_t list_bound;             // host-side bound of the list length of the step in flight: min(2B, I)
   bool list_reset_cnt;            // list mode: k_cast_W_rows resets cntI (no exclusive-row fast path on the item side)
   bool W_dirty;                   // the fp32 W table is not all-zero (left so by a dense fp32-feature step)
+  int32_t *slist, *slist_n;       // sgd fast path: list of the batch's SHARED rows (kind << 30 | row), two alternating cursors
+  int slist_slot;
   int SK_step;                    // split-K slabs written by this step's backward projection (<= SK)
   int num_cu;                     // compute units of the device (balanced forward grid)
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)

@@ -40,6 +40,11 @@ struct SparseArgs {
   const int32_t *seg_ptr;    // [I]  first entry of the item's segment
   int2 *seg_ent;             // [2B] {user | role << 31, g_b}
   int32_t *hot_done;         // [I]  finished chunks of a hot item (k_item_seg's last-finisher hand-off), all-zero between steps
+  // shared-row list (sgd fast path): the occurrence that marks a shared row first appends it (kind << 30 | row); the apply
+  // pass then walks this list instead of every occurrence of the batch
+  int32_t *slist, *slist_n;
+  int use_list;
+  int reg_items;             // exclusive item rows stored from the forward pass's registers (G >= 32, BPRMF)
 };
 
 constexpr int SEG_CAP = 32;   // entries of one item walked by ONE lane group; hotter items are cut into chunks of SEG_CAP
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
                                                    int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI,
                                                    int32_t *__restrict__ rank, int32_t *__restrict__ seg_cursor,
                                                    uint4 *__restrict__ zero16, size_t nzero16,
-                                                   int32_t *__restrict__ ilist, int32_t *__restrict__ ilist_n, int ilist_cap) {
+                                                   int32_t *__restrict__ ilist, int32_t *__restrict__ ilist_n, int ilist_cap,
+                                                   int32_t *__restrict__ slist, int32_t *__restrict__ slist_n, int slist_cap) {
   // housekeeping that would otherwise be two hipMemsetAsync launches (5-6 us each on the trace): the segment cursor, and
   // the bf16 W image of the previous step (consumed by its backward projection), re-zeroed for k_item_seg
   if (seg_cursor && blockIdx.x == 0 && threadIdx.x == 0) *seg_cursor = 0;
@@ -130,37 +136,50 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = b < B;
   const int u = valid ? clamp_quiet(user[b], U) : 0, i = valid ? clamp_quiet(pos[b], I) : 0, j = valid ? clamp_quiet(neg[b], I) : 0;
-  if (valid && doU) atomicAdd(cntU + u, 1);
-  if (!rank && !ilist) {
+  if (!rank && !ilist && !slist) {
+    if (valid && doU) atomicAdd(cntU + u, 1);
     if (valid && doI) { atomicAdd(cntI + i, 1); atomicAdd(cntI + j, 1); }
     return;
   }
   if (!rank) {
-    // List mode (sparse batches): the occurrence that finds its item's count at zero appends the item to the list of
-    // the batch's distinct items.  The appends of a workgroup are prefix-summed and take ONE atomic on the list cursor.
-    __shared__ int lw[4], lbase;
+    // The count atomics RETURN here (three independent ones per thread, in flight together) and the value tells what else
+    // this occurrence has to do:
+    //   ilist (list mode, sparse VBPR batches): it found its item's count at 0 -> it appends the item to the list of the
+    //         batch's distinct items;
+    //   slist (sgd exclusive-row fast path): it found a row's count at 1 -> the row is SHARED and exactly this occurrence
+    //         lists it (kind << 30 | row) for the apply pass, which then walks that list instead of every occurrence.
+    // The appends of a workgroup are prefix-summed and take ONE atomic per list cursor.
+    __shared__ int lw[2][4], lbase[2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    bool ai = false, aj = false;
+    bool ai = false, aj = false, su = false, si = false, sj = false;
     if (valid) {
-      ai = atomicAdd(cntI + i, 1) == 0;
-      aj = atomicAdd(cntI + j, 1) == 0;                   // i == j: the second add returns 1
+      int ou = -1, oi = -1, oj = -1;
+      if (doU) { if (slist) ou = atomicAdd(cntU + u, 1); else atomicAdd(cntU + u, 1); }
+      if (doI) { oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1); }     // i == j: the second add returns one more
+      ai = ilist && oi == 0; aj = ilist && oj == 0;
+      su = slist && ou == 1; si = slist && oi == 1; sj = slist && oj == 1;
     }
-    const unsigned long long mi = __ballot(ai), mj = __ballot(aj);
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const int pre = __popcll(mi & below) + __popcll(mj & below);
-    if (lane == 0) lw[w] = __popcll(mi) + __popcll(mj);
+    const unsigned long long mi = __ballot(ai), mj = __ballot(aj), nu = __ballot(su), ni = __ballot(si), nj = __ballot(sj);
+    const int pre0 = __popcll(mi & below) + __popcll(mj & below);
+    const int pre1 = __popcll(nu & below) + __popcll(ni & below) + __popcll(nj & below);
+    if (lane == 0) { lw[0][w] = __popcll(mi) + __popcll(mj); lw[1][w] = __popcll(nu) + __popcll(ni) + __popcll(nj); }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const int tot = lw[0] + lw[1] + lw[2] + lw[3];
-      lbase = tot ? atomicAdd(ilist_n, tot) : 0;
+    if (threadIdx.x < 2) {
+      const int q = threadIdx.x, tot = lw[q][0] + lw[q][1] + lw[q][2] + lw[q][3];
+      lbase[q] = tot ? atomicAdd(q == 0 ? ilist_n : slist_n, tot) : 0;
     }
     __syncthreads();
-    int at = lbase + pre;
-    for (int q = 0; q < w; ++q) at += lw[q];
-    if (ai) { if (at < ilist_cap) ilist[at] = i; ++at; }
-    if (aj) { if (at < ilist_cap) ilist[at] = j; }
+    int at0 = lbase[0] + pre0, at1 = lbase[1] + pre1;
+    for (int q = 0; q < w; ++q) { at0 += lw[0][q]; at1 += lw[1][q]; }
+    if (ai) { if (at0 < ilist_cap) ilist[at0] = i; ++at0; }
+    if (aj) { if (at0 < ilist_cap) ilist[at0] = j; }
+    if (su) { if (at1 < slist_cap) slist[at1] = u; ++at1; }
+    if (si) { if (at1 < slist_cap) slist[at1] = i | (1 << 30); ++at1; }
+    if (sj) { if (at1 < slist_cap) slist[at1] = j | (1 << 30); }
     return;
   }
+  if (valid && doU) atomicAdd(cntU + u, 1);
   // Ranks: the workgroup's 512 occurrences are first counted per item in an LDS hash table (LDS atomics), then ONE global
   // returning atomic per distinct item and workgroup fetches the base rank.  A hot item (Zipf popularity: thousands of
   // occurrences per batch) then costs one same-address global atomic per workgroup instead of one per occurrence
@@ -256,7 +275,7 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   if (VEC) {
     for (int c = lane * 4; c < k; c += G * 4) {
       float4 p = ld4(gu + c), q = ld4(gi + c), r = ld4(gj + c);
-      if (SEG && G >= 32) { fp = p; fq = q; fr = r; }
+      if (G >= 32) { fp = p; fq = q; fr = r; }
       si += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
       sj += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
       nrm += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w + q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w +
@@ -273,7 +292,7 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
     if (VEC) {
       for (int c = lane * 4; c < d; c += G * 4) {
         float4 p = ld4(tu + c), q = ld4(Pi + c), r = ld4(Pj + c);
-        if (SEG && G >= 32) { tp = p; tq = q; tr = r; }
+        if (G >= 32) { tp = p; tq = q; tr = r; }
         ti += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
         tj += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
         nrm += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
@@ -312,6 +331,19 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   }
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
+    if (a.use_list) {
+      // shared rows were listed for the apply pass by k_row_count (the occurrence that found the count at one); exclusive
+      // rows (finished by this group alone) reset their multiplicity here -- nobody else looks at it
+      if (exU) a.cntU[u] = 0;
+      if (iaI) {
+        if (exI) { a.wBi[i] = bi - lr * (g + r2 * bi); a.cntI[i] = 0; }
+        else atomicAdd(a.dBi + i, g + r2 * bi);
+      } else a.seg_ent[a.seg_ptr[i] + rkI] = make_int2(u, __float_as_int(g));
+      if (iaJ) {
+        if (exJ) { a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj); a.cntI[j] = 0; }
+        else atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
+      } else a.seg_ent[a.seg_ptr[j] + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
+    } else {
     if (!exU) a.flagU[u] = 1u;
     if (iaI) {
       if (exI) a.wBi[i] = bi - lr * (g + r2 * bi);
@@ -321,6 +353,7 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
       if (exJ) a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj);
       else { atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj); a.flagI[j] = 1u; }
     } else a.seg_ent[a.seg_ptr[j] + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
+    }
   }
   // ---- backward: per-occurrence gradients from the same pre-update rows (L1/L2 hits) ----
   // Lane l of the group owns elements l, l+G, ...: every atomic wave-instruction then adds G CONTIGUOUS dwords per
@@ -357,7 +390,13 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   // lane = element layout -- it is formed from the forward pass's registers (16 B per lane) and summed across the groups.
   // (wide rows only, G >= 32: at G = 16 the 27 four-byte re-reads are L1 hits and cheaper than the extra live registers:
   //  measured 38 -> 40 us on C2, 62 -> 55 us at k = d = 128, 106 -> 84 us at k = d = 256)
-  const bool from_regs = SEG && G >= 32 && VEC && wgc && !iaI && k <= 4 * G && d <= 4 * G;
+  // ... and, on the atomic path (sparse batches), also the finished rows of EXCLUSIVE items: one 16-B store per lane from
+  // the registers instead of four 4-B re-reads and four 4-B stores (C3 shard: ~88 % of the item rows).
+  const bool regs_ok = G >= 32 && VEC && k <= 4 * G && d <= 4 * G;
+  const bool from_regs = regs_ok && wgc && (SEG ? !iaI : d == 0);   // (atomic path with d > 0: the W rows are written below)
+  // (stored AFTER the element loop, which still re-reads the pre-update item rows for the user-side gradient)
+  const bool regI = !SEG && regs_ok && a.reg_items && d == 0 && iaI && exI, regJ = !SEG && regs_ok && a.reg_items && d == 0 && iaJ && exJ;
+  const bool doneI = !iaI || regI, doneJ = !iaJ || regJ;   // item rows with nothing to do in the element loop below
   if (from_regs) {
     const int c = lane * 4;
     float4 du = make_float4(g * (fq.x - fr.x) + r2 * fp.x, g * (fq.y - fr.y) + r2 * fp.y, g * (fq.z - fr.z) + r2 * fp.z,
@@ -372,27 +411,40 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
     if (lead && c < k) *reinterpret_cast<float4 *>(&s_du[wv][c]) = du;
     if (lead && c < d) *reinterpret_cast<float4 *>(&s_du[wv][k + c]) = dt;
   }
-  for (int c = lane; c < (from_regs ? 0 : k); c += G) {
+  // (wave-uniform trip count: the shuffles below need every lane; groups with nothing left skip their row parts)
+  const bool skip_loop = from_regs && __all(doneI && doneJ);
+  for (int c = lane; c < (skip_loop ? 0 : k); c += G) {
     const float p = gu[c], q = gi[c], r = gj[c];
-    float du = g * (q - r) + r2 * p;
-    if (exU) pu[c] = p - lr * du;
-    else if (wgc) {
+    if (!from_regs) {
+      float du = g * (q - r) + r2 * p;
+      if (exU) pu[c] = p - lr * du;
+      else if (wgc) {
 #pragma unroll
-      for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
-      if (lead) s_du[wv][c] = du;
-    } else if (comb) {
+        for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
+        if (lead) s_du[wv][c] = du;
+      } else if (comb) {
 #pragma unroll
-      for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
-      if (lead) atomicAdd(au + c, du);
-    } else atomicAdd(au + c, du);
-    if (iaI) {
+        for (int o = G; o < 64; o <<= 1) du += __shfl_xor(du, o, 64);
+        if (lead) atomicAdd(au + c, du);
+      } else atomicAdd(au + c, du);
+    }
+    if (!doneI) {
       const float di = g * p + r2 * q;
       if (exI) pi[c] = q - lr * di; else atomicAdd(ai + c, di);
     }
-    if (iaJ) {
+    if (!doneJ) {
       const float dj = -g * p + r2 * r;
       if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj);
     }
+  }
+  if (regI || regJ) {
+    const int c = lane * 4;
+    if (regI && c < k)
+      *reinterpret_cast<float4 *>(pi + c) = make_float4(fq.x - lr * (g * fp.x + r2 * fq.x), fq.y - lr * (g * fp.y + r2 * fq.y),
+                                                        fq.z - lr * (g * fp.z + r2 * fq.z), fq.w - lr * (g * fp.w + r2 * fq.w));
+    if (regJ && c < k)
+      *reinterpret_cast<float4 *>(pj + c) = make_float4(fr.x - lr * (-g * fp.x + r2 * fr.x), fr.y - lr * (-g * fp.y + r2 * fr.y),
+                                                        fr.z - lr * (-g * fp.z + r2 * fr.z), fr.w - lr * (-g * fp.w + r2 * fr.w));
   }
   if (d && !from_regs) {
     float *at = a.dTu + (size_t)u * d, *pt = a.wTu + (size_t)u * d;
@@ -492,6 +544,53 @@ __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *
     }
   }
   if (kind != 0 && lane == 0) { Bi[row] -= lr * a.dBi[row]; a.dBi[row] = 0.f; }
+}
+
+// sgd over the SHARED-row list (a.use_list): k_row_count listed every row that more than one triplet of the batch uses;
+// exclusive rows were finished (and their multiplicities reset) by their own triplet.  A fixed grid strides over the list,
+// whose length is only known on the device; block 0 clears the cursor of the NEXT step (two cursors alternate).
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_apply_sgd_list(float *Gu, float *Gi, float *Bi, float *Tu, SparseArgs a,
+                                                        const int32_t *__restrict__ list, const int32_t *__restrict__ n_ptr,
+                                                        int32_t *__restrict__ n_next, int cap, float lr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_next = 0;
+  int n = *n_ptr;
+  n = n < cap ? n : cap;
+  const int lane = threadIdx.x % G;
+  const int ngroups = (int)(gridDim.x * 256 / G);
+  for (int e = (int)((blockIdx.x * 256 + threadIdx.x) / G); e < n; e += ngroups) {
+    const int ent = list[e], kind = ent >> 30, row = ent & 0x3fffffff;
+    const int k = a.k;
+    float *p = (kind == 0 ? Gu : Gi) + (size_t)row * k, *gr = (kind == 0 ? a.dGu : a.dGi) + (size_t)row * k;
+    if (VEC) {
+      for (int c = lane * 4; c < k; c += G * 4) {
+        float4 v = ld4(p + c), gg = ld4(gr + c);
+        v.x -= lr * gg.x; v.y -= lr * gg.y; v.z -= lr * gg.z; v.w -= lr * gg.w;
+        *reinterpret_cast<float4 *>(p + c) = v;
+        *reinterpret_cast<float4 *>(gr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      for (int c = lane; c < k; c += G) { p[c] -= lr * gr[c]; gr[c] = 0.f; }
+    }
+    if (kind == 0 && a.d) {
+      const int d = a.d;
+      float *t = Tu + (size_t)row * d, *gt = a.dTu + (size_t)row * d;
+      if (VEC) {
+        for (int c = lane * 4; c < d; c += G * 4) {
+          float4 v = ld4(t + c), gg = ld4(gt + c);
+          v.x -= lr * gg.x; v.y -= lr * gg.y; v.z -= lr * gg.z; v.w -= lr * gg.w;
+          *reinterpret_cast<float4 *>(t + c) = v;
+          *reinterpret_cast<float4 *>(gt + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        for (int c = lane; c < d; c += G) { t[c] -= lr * gt[c]; gt[c] = 0.f; }
+      }
+    }
+    if (lane == 0) {
+      if (kind == 0) a.cntU[row] = 0;
+      else { Bi[row] -= lr * a.dBi[row]; a.dBi[row] = 0.f; a.cntI[row] = 0; }
+    }
+  }
 }
 
 // adam_tf23, sparse-variable rule (TF-2.3 Keras Adam is NOT lazy: every row of the table decays and moves every step):
@@ -1084,6 +1183,12 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
     a.fastI = 0; a.fastU = 0; a.fast = 0;
   }
   a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
+  // shared-row list: both sides on the exclusive-row fast path (sgd, atomic staging, no exported gradients)
+  a.use_list = (h->slist && a.fastU && a.fastI && !h->graph_mode) ? 1 : 0;
+  static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
+  a.reg_items = reg_items_env;
+  a.slist = h->slist;
+  a.slist_n = h->slist ? h->slist_n + h->slist_slot : nullptr;
   return a;
 }
 
@@ -1345,7 +1450,8 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
                        a.fastU, (a.fastI || h->list_mode) ? 1 : 0, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
                        h->item_mode ? h->seg_cursor : (int32_t *)nullptr, (uint4 *)(zw ? h->Wb : nullptr),
                        zw ? (size_t)a.I * a.PS * sizeof(uint16_t) / 16 : (size_t)0,
-                       h->list_mode ? h->ilist : (int32_t *)nullptr, h->list_cur, (int)cap);
+                       h->list_mode ? h->ilist : (int32_t *)nullptr, h->list_cur, (int)cap,
+                       a.use_list ? a.slist : (int32_t *)nullptr, a.slist_n, (int)(3 * h->cfg.max_batch));
   }
   if (h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
@@ -1414,6 +1520,15 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     const int G = pick_group(a.k, a.d, vec);
     // first_kind = 1 skips the user rows (their gradients are exported to the caller: BPRX_FLAG_EXPORT_USER_GRAD)
     // item rows are finished in place by k_item_seg when that mode is on: kinds [fk, ek)
+    if (a.use_list) {
+      int64_t blocks = (3 * B * G + 255) / 256;
+      if (blocks > 1024) blocks = 1024;
+      DISPATCH_G(G, vec, k_apply_sgd_list, dim3((unsigned)blocks), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, h->slist,
+                 h->slist_n + h->slist_slot, h->slist_n + (h->slist_slot ^ 1), (int)(3 * h->cfg.max_batch), lr_t);
+      h->slist_slot ^= 1;
+      BPRX_LAUNCH_CHECK(h, "k_apply_sgd_list");
+      return BPRX_OK;
+    }
     const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
     const int ek = (h->item_mode || (h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 3;
     if (ek > fk)
