@@ -328,14 +328,14 @@ def main():
                 "triplet_grad": B * (24 * w["k"] + 28 + 8 * w["d"] + 2 * PS * 4 + 2 * PS * 4) / 1.0,
                 "apply": 3 * B * 0 + B * (12 * (w["k"] + w["d"]) + 24 * w["k"]),
             }
-            if 4 * B <= w["I"]:      # touched-item list mode: the projections move the batch's distinct rows (count known on
+            if 2 * B < w["I"]:      # touched-item list mode: the projections move the batch's distinct rows (count known on
                 kern_bytes.pop("proj_fwd"), kern_bytes.pop("proj_bwd")     # the device only): no algorithmic figure quoted
         else:
             kern_bytes = {"triplet_grad": B * (24 * w["k"] + 28), "apply": B * 36 * w["k"]}
         # HBM bytes per launch from PMC counters, measured offline with scripts/pmc.sh on this same workload and
         # committed under profiles/ (bench.py itself cannot run under rocprofv3 --pmc); null when not available
         traffic, pmc, pmc_ok = None, {}, False
-        list_mode_run = w["model"] == "vbpr" and 4 * B <= w["I"]      # libbprx's per-step policy (touched-item list)
+        list_mode_run = w["model"] == "vbpr" and 2 * B < w["I"]      # libbprx's per-step policy (touched-item list)
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
             pmc_ok = args.workload == "c2" and B == WORKLOADS["c2"]["B"] and args.optimizer == "sgd"

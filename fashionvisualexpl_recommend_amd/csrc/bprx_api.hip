@@ -161,7 +161,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   }
   // Touched-item list (sparse batches): when the batch touches few of the items, both projections run over the batch's
   // distinct items only (the reference gathers 2B feature rows per step, VBPR.py:78; its own default is --batch_size 256,
-  // train_rec.py:23) instead of streaming all of F twice.  Per step: list mode iff 4B <= I (at most half of the rows);
+  // train_rec.py:23) instead of streaming all of F twice.  Per step: list mode iff 2B < I, i.e. whenever the batch cannot touch every item (measured on C2's tables: B = 16 384 / 24 576:
+  // 0.182 / 0.223 ms with the list, 0.231 / 0.239 ms streaming; B = 32 768 = 2B >= I: 0.287 vs 0.240 ms with occurrence segments);
   // BPRX_LIST_MODE = 0 never / 1 per step / 2 always.
   h->list_policy = vb ? 1 : 0;
   if (const char *e = getenv("BPRX_LIST_MODE")) { const int v = atoi(e); h->list_policy = vb ? (v < 0 ? 0 : (v > 2 ? 2 : v)) : 0; }
@@ -362,7 +363,7 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     }
   }
   // list mode: both projections over the batch's distinct items only (needs the index pass BEFORE the forward projection)
-  h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 4 * B <= (int64_t)h->cfg.num_items));
+  h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
   h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
   h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
   const bool fork_index = vb && !h->list_mode && !h->proj_fresh && h->side && h->side_mode == 2;
@@ -497,7 +498,7 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   const bool can_graph = h->graph_mode && h->cfg.optimizer == BPRX_OPT_SGD && !h->prof && stream != nullptr && !h->side &&
                          h->bound && B > 0 && B <= h->cfg.max_batch && user && pos && neg && !h->proj_fresh && !h->pending_B &&
                          h->cfg.feat_dtype != BPRX_F_FP8 &&
-                         (h->list_policy == 0 || (h->list_policy == 1 && 4 * B > (int64_t)h->cfg.num_items));   // list cursors alternate on the host
+                         (h->list_policy == 0 || (h->list_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));   // list cursors alternate on the host
   if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
   hipStream_t s = (hipStream_t)stream;
   const bool same = h->graph_exec && h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg &&

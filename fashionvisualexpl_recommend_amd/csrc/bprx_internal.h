@@ -61,8 +61,8 @@ struct bprx_handle {
   int32_t *seg_cursor;            // [1] bump allocator of segments
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
-  // touched-item list (sparse batches, 4B <= I): both projections run over the batch's DISTINCT items only
-  int list_policy;                // 0 never, 1 per step (4B <= I), 2 always (env BPRX_LIST_MODE)
+  // touched-item list (sparse batches, 2B < I): both projections run over the batch's DISTINCT items only
+  int list_policy;                // 0 never, 1 per step (2B < I), 2 always (env BPRX_LIST_MODE)
   int list_mode;                  // this step
   int32_t *ilist;                 // [min(2*max_batch, I)] distinct items of the batch, in arrival order (k_row_count)
   int32_t *ilist_n;               // [2] their number, two cursors used by alternate list-mode steps: k_dense_update (the
