@@ -6,7 +6,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import _dist_timing_patch  # noqa: F401  (host-side phase timers)
+# (the host-side phase timers this script used were a scratch monkey-patch, removed in round 2)
 from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
 from fashionvisualexpl_recommend_amd.engine import EpochWalkSampler
 
