@@ -109,6 +109,45 @@ def test_list_mode_steps_match_oracle_at_50k_items(B, dtype, opt):
     e.sync_check()
 
 
+@pytest.mark.parametrize("k,d,D,dtype,opt", [(5, 3, 100, "fp32", "sgd"), (7, 1, 64, "fp32", "adam_tf23"),     # odd widths: scalar lanes
+                                             (16, 20, 128, "bf16", "sgd"),                                     # ONE k-chunk: 7 idle waves
+                                             (16, 20, 256, "fp8", "sgd"),                                      # fp8: one 256-byte chunk
+                                             (8, 143, 384, "bf16", "sgd"), (8, 200, 512, "bf16", "adam_tf23"),   # 9 / 13 column tiles
+                                             (8, 256, 512, "fp8", "sgd")])                                     # 17 column tiles
+def test_list_mode_odd_shapes_match_oracle(k, d, D, dtype, opt):
+    """The row-list kernels at the edges of their templates: widths that are no multiple of 4, a single k-chunk (fewer
+    chunks than waves), every column-tile count class of k_proj_fwd_rows (split / full, 1..17 tiles)."""
+    U, I, B = 300, 1500, 96
+    t = _tables(U, I, k, d, D, seed=31, dtype=dtype)
+    lr = 0.05 if opt == "sgd" else 0.01
+    e = _engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype=dtype, optimizer=opt,
+                lr=lr, reg=1e-3, max_batch=B).bind(**t)
+    o = orc.OracleModel(**t, quant=QUANT[dtype])
+    rt, at = (2e-5, 2e-6) if dtype == "fp32" else (2e-3, 1e-4)
+    if opt != "sgd":
+        at = max(at, 2e-3 * lr)
+    for step in range(3):
+        if dtype != "fp32":
+            _resync(o, e, opt)
+        u, i, j = _batch(U, I, B, 500 + step)
+        loss = e.step(_dev(u), _dev(i), _dev(j)).item()
+        want = o.step(u, i, j, opt, lr, 1e-3)
+        assert loss == pytest.approx(want, rel=1e-4 if dtype != "fp32" else 2e-5)
+        # adam: lr_t*m/(sqrt(v)+eps) is steep in g around |g| ~ eps -- an element whose gradient nearly cancels (an item that
+        # is positive in one triplet and negative in another) can move by a visible fraction of lr on a last-bit difference
+        of, oa = ((1e-3, 3 * lr) if opt != "sgd" else (0.0, 0.0)) if dtype == "fp32" else \
+            ((1e-3, 3 * lr) if opt != "sgd" else (3e-2, 1e-2 * lr))
+        for n in ("Gu", "Gi", "Bi", "Tu", "E", "Bp"):
+            _close(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rt, at, "%s step %d" % (n, step), of, oa)
+    if dtype != "fp32" or opt != "sgd":
+        _resync(o, e, opt)
+    u, i, _ = _batch(U, I, 64, 9)
+    st, sa = (1e-5, 1e-6) if dtype == "fp32" else ((1e-4, 2e-5) if dtype == "bf16" else (2e-4, 5e-5))
+    _close(e.score_pairs(u, i).cpu().numpy(), o.score_pairs(u, i), st, sa, "score_pairs")
+    _close(e.score_block(0, 64).cpu().numpy(), o.predict_all()[:64], st * 10, sa * 10, "predict_all rows")
+    e.sync_check()
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp8"])
 def test_list_mode_equals_dense_mode(monkeypatch, dtype):
     """Same inputs through BPRX_LIST_MODE=0 (both projections stream every item) and =2 (distinct items only)."""
