@@ -1105,6 +1105,134 @@ __global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// forward v10: v8's balanced one-workgroup-per-CU shape, but the A operand arrives as CONTIGUOUS pieces of the tiled F --
+// a 16-row tile x 128-column chunk is one contiguous 4-KB run, lane l moves 16 B at l*16 (+1 KB per load), exactly the load
+// shape of the backward kernel (which streams F at the device's ceiling) -- into a WAVE-PRIVATE LDS area, from which the
+// MFMA fragments are read back with ds_read_b128.  v8's fragment loads take 16 rows x 64 B per instruction: half of every
+// 128-B line per instruction, every line requested by two instructions.  Nothing of A is shared between waves, so the
+// detour costs no barrier (v9 tried this load shape with a workgroup-shared image and two barriers per chunk and lost).
+// Plain C++ with scheduling fences; B as in v8 (chunk through a double-buffered shared LDS image, one barrier per chunk).
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int MT, bool F8>
+__device__ __forceinline__ void v10_body(const uint16_t *const (&asrc)[2], const uint16_t *__restrict__ Et, unsigned char *lds,
+                                         unsigned char *myA, f32x4 (&acc)[2][NT], int D, int cshift, int lane, int et_chunk) {
+  constexpr int BSB = (KC + 16) * 2;                    // B row stride in bytes (288)
+  constexpr int BBUF = NT * 16 * BSB;                   // one B buffer
+  constexpr int KS = KC / 32;
+  constexpr int NPIECE = NT * 16 * (KC / 8);
+  const int tid = threadIdx.x, bdim = (int)blockDim.x;
+  const int r = lane & 15, q = lane >> 4;
+  const int nch = D / KC;
+  i32x4_t aX[MT][4], aY[MT][4];
+  constexpr int NBR = (NPIECE + 319) / 320;             // B pieces per thread for the smallest workgroup (5 waves)
+  i32x4_t bst[NBR];
+#define V10_ISSUE(c_, AR)                                                                                             \
+  {                                                                                                                   \
+    int ce_ = (c_) + cshift;                                                                                          \
+    if (ce_ >= nch) ce_ -= nch;                                                                                       \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int x = 0; x < 4; ++x)                   \
+        AR[mt][x] = *reinterpret_cast<const i32x4_t *>(asrc[mt] + ((size_t)ce_ << 12) + x * 512 + lane * 8);          \
+    const uint16_t *bc_ = Et + (size_t)ce_ * et_chunk;                                                                \
+    _Pragma("unroll") for (int x = 0; x < NBR; ++x) {                                                                 \
+      int pc = tid + x * bdim;                                                                                        \
+      pc = pc < NPIECE ? pc : NPIECE - 1;                                                                             \
+      bst[x] = *reinterpret_cast<const i32x4_t *>(bc_ + pc * 8);                                                      \
+    }                                                                                                                 \
+  }
+#define V10_PARK(buf_)                                                                                                \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int x = 0; x < NBR; ++x) {                                                                 \
+      int pc = tid + x * bdim;                                                                                        \
+      pc = pc < NPIECE ? pc : NPIECE - 1;                                                                             \
+      *reinterpret_cast<i32x4_t *>(lds + (buf_) * BBUF + (pc / (KC / 8)) * BSB + (pc % (KC / 8)) * 16) = bst[x];      \
+    }                                                                                                                 \
+  }
+#define V10_COMPUTE(buf_, AR)                                                                                         \
+  {                                                                                                                   \
+    /* A pieces -> wave-private image (row = x*4 + lane/16, 16-B column lane%16), then the fragments back */         \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int x = 0; x < 4; ++x)                   \
+        *reinterpret_cast<i32x4_t *>(myA + (mt * 16 + x * 4 + (lane >> 4)) * BSB + (lane & 15) * 16) = AR[mt][x];      \
+    i32x4_t af[KS][MT];                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
+        af[ks][mt] = *reinterpret_cast<const i32x4_t *>(myA + (mt * 16 + r) * BSB + ks * 64 + q * 16);                \
+    const unsigned char *bl_ = lds + (buf_) * BBUF + r * BSB + q * 16;                                                \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                             \
+        const i32x4_t b = *reinterpret_cast<const i32x4_t *>(bl_ + nt * 16 * BSB + ks * 64);                          \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_frag<F8>(af[ks][mt], b, acc[mt][nt]);    \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+  V10_ISSUE(0, aX)
+  V10_PARK(0)
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {                    // nch is even; the last prefetch re-reads chunk nch-1
+    V10_ISSUE(c + 1, aY)
+    __builtin_amdgcn_sched_barrier(0);
+    V10_COMPUTE(0, aX)
+    __builtin_amdgcn_sched_barrier(0);
+    V10_PARK(1)
+    __syncthreads();
+    const int cn = c + 2 < nch ? c + 2 : nch - 1;
+    V10_ISSUE(cn, aX)
+    __builtin_amdgcn_sched_barrier(0);
+    V10_COMPUTE(1, aY)
+    __builtin_amdgcn_sched_barrier(0);
+    V10_PARK(0)
+    __syncthreads();
+  }
+  // (A two chunks ahead -- three register sets in rotation, 128 KB per CU in flight -- was measured SLOWER: 85.0 vs 80.2 us
+  //  on C2, 129.5 vs 115.8 us (v8) on the c4 shard; removed)
+#undef V10_ISSUE
+#undef V10_PARK
+#undef V10_COMPUTE
+}
+
+template <int NT, bool F8>
+__global__ __launch_bounds__(512) void k_proj_fwd_bf16_v10(const uint16_t *__restrict__ F, int nrows, int D,
+                                                           const uint16_t *__restrict__ Et, float *__restrict__ P, int PS,
+                                                           const float *__restrict__ pscale, int stagger, int tiles_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_v10[];   // Bs[2] | As[waves][2 tiles][16 rows][288 B]
+  constexpr int BSB = (KC + 16) * 2;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int T = (nrows + 15) >> 4;
+  const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
+  const int first = t0 + w * tiles_per_wave;
+  const int nlive = (first < t1 ? 1 : 0) + ((tiles_per_wave == 2 && first + 1 < t1) ? 1 : 0);   // wave-uniform
+  const uint16_t *asrc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int tile = first + mt;
+    if (tile >= t1) tile = t1 > t0 ? t1 - 1 : 0;         // only read by a wave without work
+    asrc[mt] = F + ft_row(tile * 16, D);                 // the tile's 16 rows x 128 columns: 4 KB contiguous (rows past the
+  }                                                      // end of the table are zero rows of the tiled copy)
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nch = D / KC;
+  const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
+  unsigned char *myA = lds_v10 + 2 * NT * 16 * BSB + w * (2 * 16 * BSB);
+  if (nlive == 2) v10_body<NT, 2, F8>(asrc, Et, lds_v10, myA, acc, D, cshift, lane, PS * 128);
+  else v10_body<NT, 1, F8>(asrc, Et, lds_v10, myA, acc, D, cshift, lane, PS * 128);
+  const float ps = F8 ? *pscale : 1.0f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (mt >= nlive) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int t = (first + mt) * 16 + q * 4 + reg;
+      if (t < nrows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // forward, fp8 features, WIDE projections (NT >= 10 column tiles: BASELINE.json configs[4], k = d = 256 -> PS = 272) in ONE
 // pass over F on the block-scaled fp8 MFMA.  The v8 kernel keeps two waves per SIMD (256 registers each) and therefore
 // covers at most nine column tiles per launch: d = 256 took three column-range launches, i.e. three reads of F, on the
@@ -1457,6 +1585,39 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
       (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(512), lds, s, (const unsigned char *)h->Ft, (int)nrows, h->cfg.feat_dim,
                          (const unsigned char *)h->EtS, Pout, h->PS, pscale, stg & 1);
+      return 0;
+    }
+  }
+  if constexpr (NT <= 9) {
+    // v10 (A through a wave-private LDS image, contiguous loads): the default for bf16 tables up to six column tiles --
+    // C2: 76.7-80.2 us against v8's 83.4-87.2 us on the same boxes (5.3-5.6 TB/s); not for fp8 tables (c2fp8: 45.0 vs
+    // 41.7 us) nor wider projections (c4 shard, nine tiles: 117.9 vs 110.7 us).  BPRX_FWD_LDS=0 keeps v8; variant 6 / 14
+    // forces v10 (+ staggered chunk order: 78.0 vs 76.7 us).
+    const bool lds_default = v == 4 && !f8 && NT <= 6 && !(getenv("BPRX_FWD_LDS") && atoi(getenv("BPRX_FWD_LDS")) == 0);
+    const int stg10 = v == 6 ? (stg & 1) : 0;
+    if ((v == 6 || lds_default) && Deq % 256 == 0 && !rows) {
+      constexpr int NWMAX = 8, NWMIN = 5;
+      const int64_t T = (nrows + 15) / 16;
+      const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+      int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
+      if (G < ncu) G = T < ncu ? T : ncu;
+      else G = (G + ncu - 1) / ncu * ncu;
+      const int tpw_max = (int)((T + G - 1) / G);
+      const int per_wave = tpw_max > NWMAX ? 2 : 1;
+      int nw = (tpw_max + per_wave - 1) / per_wave;
+      if (nw < NWMIN) nw = NWMIN;
+      const size_t lds = (size_t)2 * NT * 16 * 288 + (size_t)nw * 2 * 16 * 288;
+      if (f8) {
+        auto kfn = k_proj_fwd_bf16_v10<NT, true>;
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, (const uint16_t *)h->Ft, (int)nrows, Deq,
+                           (const uint16_t *)h->Et, Pout, h->PS, pscale, stg10, per_wave);
+      } else {
+        auto kfn = k_proj_fwd_bf16_v10<NT, false>;
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, (const uint16_t *)h->Ft, (int)nrows, Deq,
+                           (const uint16_t *)h->Et, Pout, h->PS, pscale, stg10, per_wave);
+      }
       return 0;
     }
   }

@@ -40,7 +40,7 @@ def mfma_busy(m):
 
 
 if json_out:
-    phases = {"proj_fwd": "k_proj_fwd_bf16_v8", "proj_bwd": "k_proj_bwd_bf16_v3", "triplet_grad": "k_triplet_grad",
+    phases = {"proj_fwd": "k_proj_fwd_bf16_v", "proj_bwd": "k_proj_bwd_bf16_v3", "triplet_grad": "k_triplet_grad",
               "item_seg": "k_item_seg", "dense_update": "k_dense_update", "row_count": "k_row_count", "apply": "k_apply_sgd"}
     out = {}
     for ph, pat in phases.items():

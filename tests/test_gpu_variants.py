@@ -67,7 +67,8 @@ def test_safe_table_is_not_empty():
 
 @pytest.mark.parametrize("I", [50_000, 20_000])
 def test_every_safe_instantiation_matches_the_plain_kernel(monkeypatch, I):
-    checked = 0
+    monkeypatch.setenv("BPRX_FWD_LDS", "0")               # the v8 instantiations themselves (the default for narrow bf16
+    checked = 0                                           # projections is the LDS-staged v10, tested below)
     for ver, nt, mt, rem in _safe():
         fp8 = ver == 8 and rem == 1
         d = 16 * nt - 1                                   # PS = 16 * nt: exactly this instantiation
@@ -84,6 +85,18 @@ def test_every_safe_instantiation_matches_the_plain_kernel(monkeypatch, I):
         assert float((stag - plain).abs().max()) <= tol, (ver, nt, mt, fp8, I, float((stag - plain).abs().max()), tol)
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("I", [50_000, 20_000, 3_000])
+@pytest.mark.parametrize("d,fp8", [(15, False), (64, False), (79, True), (128, False), (143, True)])
+def test_lds_staged_forward_v10_matches_the_plain_kernel(monkeypatch, I, d, fp8):
+    """BPRX_FWD_VARIANT=6 / 14: the A operand through a wave-private LDS image with contiguous loads (k_proj_fwd_bf16_v10)."""
+    t = _state(I, d, fp8, seed=7 * d + I % 97)
+    plain = _scores(monkeypatch, 0, I, d, fp8, t)
+    got = _scores(monkeypatch, 6, I, d, fp8, t)
+    assert torch.equal(got, plain), (I, d, fp8, int((got != plain).sum()), float((got - plain).abs().max()))
+    stag = _scores(monkeypatch, 14, I, d, fp8, t)
+    assert float((stag - plain).abs().max()) <= 2e-6 * float(plain.abs().max()) + 1e-9
 
 
 @pytest.mark.parametrize("d,fp8", [(200, False), (256, False), (256, True), (160, True)])
