@@ -395,7 +395,7 @@ def main():
             if args.cpu_eager_seconds > 0:
                 out["cpu_baseline_eager"] = cpu_baseline_eager(w, tables, args.cpu_eager_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

@@ -8,7 +8,7 @@ for spec in "$@"; do
   timeout -k 10 300 python bench.py --no-cpu-baseline $args > gpurun_out/bench_$name.log 2>&1
   rc=$?
   echo "== $name rc=$rc"
-  tail -1 gpurun_out/bench_$name.log | python -c "
+  grep "^{\"metric\"" gpurun_out/bench_$name.log | tail -1 | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read())

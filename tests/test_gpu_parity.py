@@ -138,6 +138,30 @@ def test_vbpr_score_pairs_and_predict(k, d, D, dtype):
     e.sync_check()
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 4e-3), ("fp8", 6e-2)])
+def test_reduced_precision_features_against_the_fp32_reference_formula(dtype, tol):
+    """What the bf16 / fp8 feature paths cost against the REFERENCE's fp32 arithmetic (VBPR.py:82-84 on unrounded F, E,
+    Bp) -- the other bf16/fp8 tests compare with the oracle's twin that rounds the same operands.  The visual term
+    theta_u.(f_i E) + f_i.Bp is a 4096-term dot product of operands rounded to 8 (bf16) / 4 (e4m3) significant bits:
+    its error relative to the term's own magnitude stays within `tol` (bf16: 2^-9 per operand, averaging over 4096
+    terms; fp8: 2^-4 per operand), and the full score inherits it in proportion to the visual term's share."""
+    U, I, k, d, D, B = 40, 300, 64, 64, 4096, 500
+    t = _tables(U, I, k, d, D, seed=12)                                   # F in fp32, not pre-rounded
+    e = _engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype=dtype,
+                optimizer="sgd", max_batch=B).bind(**t)
+    u, i, _ = _batch(U, I, B, 4)
+    got = e.score_pairs(u, i).cpu().numpy().astype(np.float64)
+    o = orc.OracleModel(**t, quant=0)                                      # the reference formula in fp32 / fp64
+    want = o.score_pairs(u, i).astype(np.float64)
+    F, E, Bp, Tu = (t[n].astype(np.float64) for n in ("F", "E", "Bp", "Tu"))
+    vis = np.einsum("bd,bd->b", Tu[u], F[i] @ E) + F[i] @ Bp              # the visual term alone
+    err = np.abs(got - want)
+    scale = np.abs(vis).mean()
+    assert err.max() <= tol * max(scale, 1e-6) * 4, (err.max(), scale)
+    assert err.mean() <= tol * max(scale, 1e-6), (err.mean(), scale)
+    e.sync_check()
+
+
 @pytest.mark.parametrize("k,d,D,dtype,opt,reg", [(32, 20, 128, "fp32", "sgd", 1e-3), (32, 20, 128, "fp32", "adam_tf23", 1e-3),
                                                  (8, 5, 100, "fp32", "sgd", 0.0),
                                                  # the reference's own shape and precision: 4096-d fc2 features in fp32,
