@@ -500,7 +500,10 @@ __device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t w, uint32_t &o0, uint32
 // (rows indexed by item id, as k_triplet_grad accumulated them; rounded to bf16 on the way into LDS -- no conversion
 // pass), the list length comes from the device (*nrows_dev; `nrows` is the host-side bound) and the item splits are cut
 // from it here.
-template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS = false>
+// DB = 2: two LDS images used by alternate tiles -- the barrier that protects an image from being overwritten while other
+// waves still read it disappears (one barrier per tile instead of two) and a wave's commit of tile t+1 (for fp8 tables:
+// the widening to bf16) overlaps the other waves' MFMAs of tile t.  For the MFMA-paced shapes (fp8 tables, wide projections).
+template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS = false, int DB = 1>
 __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
                                                           const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
                                                           int rows_per_split, int descend, int xcd_map,
@@ -517,8 +520,9 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
   static_assert(CBK >= 1 && BTV % 32 == 0 && (BTV * FCH) % NTH == 0, "tile must be whole 8-KB blocks");
   constexpr int WCH = NT * 2;                        // 16-B pieces per W row
   constexpr int WPT = (BTV * WCH + NTH - 1) / NTH;
-  __shared__ __attribute__((aligned(16))) unsigned char Fs[BTV * FSB];
-  __shared__ __attribute__((aligned(16))) unsigned char Ws[BTV * WSB];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_bwd3[];   // DB x (F image | W image)
+  constexpr int IMG = BTV * FSB + BTV * WSB;
+  unsigned char *const Fs0 = lds_bwd3, *const Ws0 = lds_bwd3 + BTV * FSB;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
   // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (own L2 each) in dispatch order.  The
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
 #define BWD3_COMMIT(ST, TILE)                                                                                            \
   {                                                                                                                      \
     const int tile_ = (TILE);                                                                                            \
+    unsigned char *const Fs = Fs0 + (DB == 2 ? (tile_ & 1) * IMG : 0), *const Ws = Ws0 + (DB == 2 ? (tile_ & 1) * IMG : 0); \
     const int t0 = tile_ < ntiles ? tbeg + (descend ? (ntiles - 1 - tile_) : tile_) * BTV : tend;                        \
     _Pragma("unroll") for (int x = 0; x < FPT; ++x) {                                                                    \
       const int pp = threadIdx.x + x * NTH, blk = pp >> 9;                                                               \
@@ -631,10 +636,11 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
   for (int tile0 = 0; tile0 < ntiles; tile0 += PD) {
 #pragma unroll
    for (int st = 0; st < PD; ++st) {                 // tiles past the end are all-zero: computed, harmless
-    __syncthreads();
-    BWD3_COMMIT(st, tile0 + st)
+    if (DB == 1) __syncthreads();                     // (DB == 2: the image of tile t+1 was last read for tile t-1, and every
+    BWD3_COMMIT(st, tile0 + st)                       //  wave has passed tile t's barrier since)
     __syncthreads();
     BWD3_ISSUE(st, tile0 + st + PD)
+    const unsigned char *const Fs = Fs0 + (DB == 2 ? ((tile0 + st) & 1) * IMG : 0), *const Ws = Ws0 + (DB == 2 ? ((tile0 + st) & 1) * IMG : 0);
 #pragma unroll
     for (int kk = 0; kk < BTV / 32; ++kk) {
       const int rlo = kk * 32 + 8 * g + qq, rhi = rlo + 4;       // (rlo & 8) == (rhi & 8) == 8*(g & 1)
@@ -1644,6 +1650,19 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
   return 0;
 }
 
+// one launch of k_proj_bwd_bf16_v3 with its dynamic LDS size (DB images of F tile + W tile)
+template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS, int DB>
+void launch_bwd3(dim3 grid, hipStream_t s, const uint16_t *Ft, int nrows, int D, const uint16_t *Wb, int PS, float *part, int rps,
+                 int desc, int xmap, const int32_t *rows, const int32_t *nrows_dev, const float *Wf) {
+  constexpr size_t lds = (size_t)DB * (BTV * (NW * 32 * 2 + 32) + BTV * WsStride3<NT>::bytes);
+  auto kfn = k_proj_bwd_bf16_v3<NT, BTV, NW, PD, F8, ROWS, DB>;
+  if (lds > 48 * 1024) {
+    static bool attr_set = false;                        // per instantiation
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(NW * 64), lds, s, Ft, nrows, D, Wb, PS, part, rps, desc, xmap, rows, nrows_dev, Wf);
+}
+
 // backward over the touched-item list (list mode): v3 kernel in ROWS form, 2 tiles in flight; `bound` = host-side bound of
 // the list length
 template <int NT>
@@ -1653,9 +1672,9 @@ int launch_bwd_rows(bprx_handle *h, int64_t bound, hipStream_t s) {
   const bool w8 = D % 256 == 0 || f8;
   dim3 g3(D / (w8 ? 256 : 128), h->SK_step);
 #define BWDR_LAUNCH(NW_, F8_)                                                                                            \
-  hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, 32, NW_, 2, F8_, true>), g3, dim3(NW_ * 64), 0, s, (const uint16_t *)h->Ft,  \
-                     (int)bound, D, (const uint16_t *)h->Wb, h->PS, h->part, 0, 0, 1, (const int32_t *)h->ilist,        \
-                     (const int32_t *)h->list_cur, (const float *)h->W)
+  launch_bwd3<NT, 32, NW_, 2, F8_, true, 1>(g3, s, (const uint16_t *)h->Ft, (int)bound, D, (const uint16_t *)h->Wb, h->PS,     \
+                                            h->part, 0, 0, 1, (const int32_t *)h->ilist, (const int32_t *)h->list_cur,        \
+                                            (const float *)h->W)
   if (f8) BWDR_LAUNCH(8, true);
   else if (w8) BWDR_LAUNCH(8, false);
   else BWDR_LAUNCH(4, false);
@@ -1682,17 +1701,28 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
     const int pd = ((h->bwd_variant >> 4) & 3) + 1;
     const int xmap = (h->bwd_variant & 64) ? 0 : 1;   // +64: plain blockIdx mapping (A/B)
     dim3 g3(D / (w8 ? 256 : 128), h->SK);
+    // double-buffered LDS image (one barrier per tile) for the MFMA-paced shapes: fp8 tables and projections wider than nine
+    // column tiles, two tiles in flight; BPRX_BWD_DB = 0 / 1 forces it off / on wherever it is instantiated
+    bool db = (f8 || NT > 9) && pd == 2 && bt3 == 32 && w8;
+    if (const char *e = getenv("BPRX_BWD_DB")) db = atoi(e) != 0 && pd == 2 && bt3 == 32 && w8;
+#define BWD3_ARGS (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap, (const int32_t *)nullptr, \
+                  (const int32_t *)nullptr, (const float *)nullptr
 #define BWD3_LAUNCH(BTV_, NW_, PD_)                                                                                      \
   do {                                                                                                                   \
-    if constexpr (NW_ == 8) {                                                                                            \
-      if (f8) {                                                                                                          \
-        hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, 8, PD_, true>), g3, dim3(512), 0, s, (const uint16_t *)h->Ft,   \
-                           I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap);                             \
+    if constexpr (NW_ == 8 && PD_ == 2 && BTV_ == 32) {                                                                  \
+      if (db) {                                                                                                          \
+        if (f8) launch_bwd3<NT, 32, 8, 2, true, false, 2>(g3, s, BWD3_ARGS);                                             \
+        else launch_bwd3<NT, 32, 8, 2, false, false, 2>(g3, s, BWD3_ARGS);                                               \
         break;                                                                                                           \
       }                                                                                                                  \
     }                                                                                                                    \
-    hipLaunchKernelGGL((k_proj_bwd_bf16_v3<NT, BTV_, NW_, PD_, false>), g3, dim3(NW_ * 64), 0, s,                        \
-                       (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap);        \
+    if constexpr (NW_ == 8) {                                                                                            \
+      if (f8) {                                                                                                          \
+        launch_bwd3<NT, BTV_, 8, PD_, true, false, 1>(g3, s, BWD3_ARGS);                                                 \
+        break;                                                                                                           \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    launch_bwd3<NT, BTV_, NW_, PD_, false, false, 1>(g3, s, BWD3_ARGS);                                                  \
   } while (0)
 #define BWD3_PD(BTV_, NW_)                                        \
   switch (pd) {                                                   \
@@ -1707,6 +1737,7 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
     else { BWD3_LAUNCH(64, 4, 1); }
 #undef BWD3_PD
 #undef BWD3_LAUNCH
+#undef BWD3_ARGS
     return 0;
   }
   int rps = (I + h->SK - 1) / h->SK;
