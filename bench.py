@@ -62,9 +62,12 @@ def parse():
                     help="N > 1, VBPR: replicated = user tables on every rank, one all-gather per step (default); "
                          "a2a = user tables range-partitioned, rows fetched / gradients returned by all-to-all")
     ap.add_argument("--dense-reduce", default="gather", choices=["gather", "allreduce"],
-                    help="N > 1, replicated mode: dE|dBp summed in rank order inside the all-gathered message (default: "
-                         "bit-identical replicas, ONE collective per step) or by a separate RCCL all-reduce (north_star's "
-                         "form: 2(N-1)/N instead of N-1 dense-gradient transfers per rank, two collectives per step)")
+                    help="N > 1, replicated mode: the ranks' dE|dBp all-gathered and summed in rank order (default: "
+                         "bit-identical replicas whatever the collective's reduction order) or summed by an RCCL all-reduce "
+                         "(north_star's form: 2(N-1)/N instead of N-1 dense-gradient transfers per rank)")
+    ap.add_argument("--no-dist-overlap", action="store_true",
+                    help="N > 1, replicated mode: the round-1 order (ONE message [user rows | dE|dBp] after the whole local "
+                         "step) instead of the user rows' all-gather travelling beside the backward projection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-overlap", action="store_true",
                     help="draw each batch one step ahead on a side stream (measured on C2: 0.287 vs 0.280 ms/step without "
@@ -185,7 +188,8 @@ def main():
             cap = B if args.sampler != "epoch" else B // args.pos_per_user + 256
             sharded = ReplicatedUserVBPR(rank, world, Gu_all, Tu_all, tables["Gi"], tables["Bi"], tables["F"], tables["E"],
                                          tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B, user_cap=cap, feat_dtype=w["dtype"],
-                                         device=local_rank, optimizer=args.optimizer, dense_reduce=args.dense_reduce)
+                                         device=local_rank, optimizer=args.optimizer, dense_reduce=args.dense_reduce,
+                                         overlap=not args.no_dist_overlap)
         else:
             from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
             sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
@@ -374,9 +378,11 @@ def main():
                                    % (args.workload, w["model"].upper(), w["k"], w["d"], w["D"], w["U"], w["I"],
                                       w["dtype"], B, args.optimizer),
                        "global_batch": B * world, "parallelism": "single" if (world == 1 and sharded is None) else
-                       ((("item-shard x%d, users replicated: one all-gather per step (distinct users' gradient rows%s), "
-                          "local negatives" % (world, " + dE|dBp" if args.dense_reduce == "gather" else
-                                               "; dE|dBp by a separate RCCL all-reduce")) if args.dist_mode == "replicated" else
+                       ((("item-shard x%d, users replicated: all-gather of the distinct users' gradient rows %s; dE|dBp %s; "
+                          "local negatives" % (world, "after the local step" if args.no_dist_overlap else
+                                               "beside the backward projection",
+                                               "all-gathered and summed in rank order" if args.dense_reduce == "gather" else
+                                               "by RCCL all-reduce")) if args.dist_mode == "replicated" else
                          ("item-shard x%d: all-to-all user rows + all-reduce(E|Bp), local negatives" % world))
                         if w["model"] == "vbpr" else ("user-shard x%d: all-to-all item rows, no all-reduce" % world)),
                        "sampler": (("device philox, uniform positive + rejection negative" if args.sampler == "philox" else

@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbprx.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2
 FLAG_DENSE_ALLREDUCE = 4
@@ -75,6 +75,8 @@ def lib():
         "bprx_score_pairs": (C.c_int, [vp, vp, vp, i64, vp, vp]),
         "bprx_step": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
         "bprx_step_begin": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+        "bprx_step_begin_sparse": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+        "bprx_step_begin_dense": (C.c_int, [vp, vp]),
         "bprx_dense_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "bprx_step_end": (C.c_int, [vp, vp, vp]),
         "bprx_step_project": (C.c_int, [vp, vp]),
@@ -94,6 +96,7 @@ def lib():
         "bprx_user_msg_floats": (C.c_int64, [vp, i64]),
         "bprx_pack_user_msg": (C.c_int, [vp, vp, i64, i64, vp, vp]),
         "bprx_apply_user_msgs": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
+        "bprx_sum_dense_parts": (C.c_int, [vp, vp, i32, vp]),
         "bprx_sample_epoch": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_uint64, u32, i64, i64, vp, vp, vp, vp]),
         "bprx_sampler_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(vp)]),
         "bprx_sampler_destroy": (C.c_int, [vp]),
@@ -111,6 +114,7 @@ def lib():
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
+           "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",

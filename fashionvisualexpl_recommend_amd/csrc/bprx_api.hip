@@ -26,7 +26,7 @@ static void graph_drop(bprx_handle *h) {
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -85,6 +85,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   A(dalloc_zero(&h->lossb, MB));
   A(dalloc_zero(&h->loss_acc, (size_t)BPRX_DENSE_BLOCKS));
   A(dalloc_zero(&h->errflag, (size_t)1));
+  if (cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) A(dalloc_zero(&h->msg_cursor, (size_t)2));
   A(dalloc_zero(&h->cntU, U));
   A(dalloc_zero(&h->cntI, I));
   if (vb) {
@@ -342,7 +343,10 @@ extern "C" int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32
   return bprx_launch_score(h, user, item, B, nullptr, 0, x, s);
 }
 
-extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, void *stream) {
+// First half of bprx_step_begin: index pass, item projections, per-triplet gradients.  Afterwards the USER-side gradients
+// of the batch are final (staging tables with BPRX_FLAG_EXPORT_USER_GRAD): a replicated-user step packs and all-gathers
+// them while bprx_step_begin_dense (item rows, W, dE|dBp = F^T W) is still running.
+extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, void *stream) {
   int rc = check_ready(h, B);
   if (rc) return rc;
   if (B == 0) BPRX_FAIL(h, BPRX_E_INVALID, "step: empty batch");
@@ -388,6 +392,21 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
   if (fork_index) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
   else if (!h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
+  h->pending_B = B;
+  h->pending_stage = 1;
+  h->pend_u = user; h->pend_i = pos; h->pend_j = neg; h->pend_lr = lr_t;
+  return BPRX_OK;
+}
+
+extern "C" int bprx_step_begin_dense(bprx_handle *h, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (!h->pending_B || h->pending_stage != 1) BPRX_FAIL(h, BPRX_E_STATE, "step_begin_dense without step_begin_sparse");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  const int32_t *user = h->pend_u, *pos = h->pend_i, *neg = h->pend_j;
+  const int64_t B = h->pending_B;
+  const float lr_t = h->pend_lr;
+  int rc;
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, lr_t, s))) return rc;                  // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
   // projection -- with VBPR it runs on the side stream beside it
@@ -402,8 +421,14 @@ extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_
     if (vb && (rc = bprx_launch_proj_bwd(h, B, s))) return rc;
     if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, s))) return rc;
   }
-  h->pending_B = B;
+  h->pending_stage = 2;
   return BPRX_OK;
+}
+
+extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, void *stream) {
+  int rc = bprx_step_begin_sparse(h, user, pos, neg, B, stream);
+  if (!rc && (rc = bprx_step_begin_dense(h, stream))) h->pending_B = 0;       // a failed _begin leaves no step pending
+  return rc;
 }
 
 extern "C" int bprx_step_project(bprx_handle *h, void *stream) {
@@ -460,6 +485,7 @@ extern "C" int bprx_dense_grad(bprx_handle *h, float **ptr, int64_t *count) {
 extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
   if (!h) return BPRX_E_INVALID;
   if (!h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_end without step_begin");
+  if (h->pending_stage != 2) BPRX_FAIL(h, BPRX_E_STATE, "step_end before step_begin_dense");
   hipStream_t s = (hipStream_t)stream;
   int rc;
   float lr_t = h->cfg.lr;

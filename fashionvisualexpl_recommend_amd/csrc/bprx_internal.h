@@ -78,6 +78,13 @@ struct bprx_handle {
   int num_cu;                     // compute units of the device (balanced forward grid)
   int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
+  int pending_stage;              // 1 = bprx_step_begin_sparse done (user gradients final), 2 = whole _begin done
+  const int32_t *pend_u, *pend_i, *pend_j;   // the pending step's index buffers (bprx_step_begin_dense)
+  float pend_lr;
+  // replicated-user message exchange (bprx_pack_user_msg / bprx_apply_user_msgs)
+  int32_t *msg_cursor;            // [2] next free slot of the message being packed, workgroups done (both zero between calls)
+  int32_t *msg_next;              // [nranks*cap] chain links of the occurrences of one user across the ranks' messages
+  size_t msg_next_n;
   // side stream: the sparse optimizer pass (k_apply_sgd / adam sweeps: factor tables only) runs beside the backward
   // projection (F, W, slabs only); forked after k_triplet_grad, joined in bprx_step_end
   hipStream_t side;

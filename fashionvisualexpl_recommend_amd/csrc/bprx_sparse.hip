@@ -1267,99 +1267,189 @@ extern "C" int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols
 
 // ---- replicated-user multi-GPU step: message packing / application (include/bprx.h) ----
 namespace {
-// msg (4-byte words): [0] count | [1, 1+cap) ids | cap*k dGu rows | cap*d dTu rows | D*d + D dense gradient
+// msg (4-byte words): [count,0,0,0 | ids[cap4] | cap*k dGu rows | cap*d dTu rows | D*d + D dense gradient], cap4 = cap
+// rounded up to 4 and the whole message to a multiple of 4 words: rows are 16-byte aligned when k and d are multiples of 4
+__host__ __device__ inline size_t msg_hdr(int64_t cap) { return 4 + (size_t)((cap + 3) & ~(int64_t)3); }
+
+template <bool VEC>
+__device__ __forceinline__ void row_move(float *__restrict__ dst, float *__restrict__ src, int n, int lane, bool keep) {
+  constexpr int G = 16;
+  if (VEC) {
+    for (int c = lane * 4; c < n; c += G * 4) {
+      if (keep) *reinterpret_cast<float4 *>(dst + c) = ld4(src + c);
+      *reinterpret_cast<float4 *>(src + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    for (int c = lane; c < n; c += G) { if (keep) dst[c] = src[c]; src[c] = 0.f; }
+  }
+}
+
+// One thread per triplet claims the triplet's user (first occurrence of a touched user owns its row); the workgroup's
+// claims are compacted through LDS and take their message slots with ONE cursor atomic (a returning atomic per claimed
+// user on a single address paced the first version: 43 us for 3 277 users).  Then 16 lanes move each claimed row.
+// The last workgroup to finish publishes the count and re-arms the cursor.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_pack_user_msg(const int32_t *__restrict__ user, int64_t B, int U, int k, int d,
                                                        int cap, uint32_t *__restrict__ flagU, float *__restrict__ dGu,
                                                        float *__restrict__ dTu, float *__restrict__ msg,
-                                                       int32_t *__restrict__ errflag) {
-  constexpr int G = 16;
-  const int64_t b = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
-  const int lane = threadIdx.x % G;
-  if (b >= B) return;
-  const int u = clamp_quiet(user[b], U);
-  unsigned claimed = 0;
-  int slot = 0;
-  if (lane == 0) {
-    claimed = atomicExch(flagU + u, 0u);                    // the first occurrence of a touched user owns its row
-    if (claimed) slot = atomicAdd(reinterpret_cast<int32_t *>(msg), 1);
+                                                       int32_t *__restrict__ cursor, int32_t *__restrict__ errflag) {
+  __shared__ int s_u[256];
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane64 = tid & 63, w = tid >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 256 + tid;
+  int u = 0;
+  bool claimed = false;
+  if (b < B) {
+    u = clamp_quiet(user[b], U);
+    claimed = atomicExch(flagU + u, 0u) != 0u;
   }
-  claimed = __shfl(claimed, 0, G);
-  slot = __shfl(slot, 0, G);
-  if (!claimed) return;
-  float *gr = dGu + (size_t)u * k, *gt = d ? dTu + (size_t)u * d : nullptr;
-  if (slot < cap) {
-    if (lane == 0) reinterpret_cast<int32_t *>(msg)[1 + slot] = u;
-    float *og = msg + 1 + cap + (size_t)slot * k, *ot = msg + 1 + cap + (size_t)cap * k + (size_t)slot * d;
-    for (int c = lane; c < k; c += G) { og[c] = gr[c]; gr[c] = 0.f; }
-    for (int c = lane; c < d; c += G) { ot[c] = gt[c]; gt[c] = 0.f; }
-  } else {                                                  // more distinct users than the message holds: reported
-    if (lane == 0) *errflag = 4;
-    for (int c = lane; c < k; c += G) gr[c] = 0.f;
-    for (int c = lane; c < d; c += G) gt[c] = 0.f;
+  const unsigned long long bal = __ballot(claimed);
+  if (lane64 == 0) s_wave[w] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { off += i < w ? s_wave[i] : 0; tot += s_wave[i]; }
+  if (claimed) s_u[off + __popcll(bal & ((1ull << lane64) - 1ull))] = u;
+  if (tid == 0) s_base = tot ? atomicAdd(cursor, tot) : 0;
+  __syncthreads();
+  const int base = s_base;
+  const size_t hdr = msg_hdr(cap);
+  const int lane = tid & 15;
+  for (int e = tid >> 4; e < tot; e += 16) {
+    const int uu = s_u[e], slot = base + e;
+    const bool keep = slot < cap;
+    if (keep) { if (lane == 0) reinterpret_cast<int32_t *>(msg)[4 + slot] = uu; }
+    else if (lane == 0) *errflag = 4;                       // more distinct users than the message holds: reported
+    const int sl = keep ? slot : 0;
+    row_move<VEC>(msg + hdr + (size_t)sl * k, dGu + (size_t)uu * k, k, lane, keep);
+    if (d) row_move<VEC>(msg + hdr + (size_t)cap * k + (size_t)sl * d, dTu + (size_t)uu * d, d, lane, keep);
+  }
+  if (tid == 0) {
+    const int prev = atomicAdd(cursor + 1, 1);
+    if (prev == (int)gridDim.x - 1) {
+      reinterpret_cast<int32_t *>(msg)[0] = atomicExch(cursor, 0);
+      cursor[1] = 0;
+    }
   }
 }
 
-// one rank's rows: ids are distinct within a message -> plain read-modify-write
-__global__ __launch_bounds__(256) void k_apply_user_msg(const float *__restrict__ msg, int cap, int U, int k, int d,
-                                                        float *__restrict__ Gu, float *__restrict__ Tu, float scale) {
-  constexpr int G = 16;
-  const int slot = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) / G), lane = threadIdx.x % G;
-  int cnt = reinterpret_cast<const int32_t *>(msg)[0];
+// Application of the gathered messages, in rank order per user whatever the number of ranks, in two launches:
+// k_msg_link chains the occurrences of a user across the ranks' messages (an exchange on the user's word `head[u]`; ids are
+// distinct within one message, so a chain has at most nranks links); in the second launch the occurrence that finds its
+// own code in head[u] owns the user: it walks the chain, and applies the rows by ascending rank (plain read-modify-write:
+// every replica performs the same additions in the same order and the replicas stay bit-identical).  head[] is the
+// touched-user mark array, all-zero after k_pack_user_msg, and is returned to zero by the owners.
+__device__ __forceinline__ bool msg_job(const float *__restrict__ msgs, int nranks, size_t stride, int cap, int U, int64_t job,
+                                        int &r, int &slot, int &u) {
+  if (job >= (int64_t)nranks * cap) return false;
+  r = (int)(job / cap); slot = (int)(job - (int64_t)r * cap);
+  const int32_t *m = reinterpret_cast<const int32_t *>(msgs + (size_t)r * stride);
+  int cnt = m[0];
   cnt = cnt < cap ? cnt : cap;
-  if (slot >= cnt) return;
-  const int u = reinterpret_cast<const int32_t *>(msg)[1 + slot];
-  if ((unsigned)u >= (unsigned)U) return;
-  const float *ig = msg + 1 + cap + (size_t)slot * k, *it = msg + 1 + cap + (size_t)cap * k + (size_t)slot * d;
+  if (slot >= cnt) return false;
+  u = m[4 + slot];
+  return (unsigned)u < (unsigned)U;
+}
+
+__global__ __launch_bounds__(256) void k_msg_link(const float *__restrict__ msgs, int nranks, size_t stride, int cap, int U,
+                                                  uint32_t *__restrict__ head, int32_t *__restrict__ next) {
+  const int64_t job = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int r, slot, u;
+  if (!msg_job(msgs, nranks, stride, cap, U, job, r, slot, u)) return;
+  next[job] = (int32_t)atomicExch(head + u, (uint32_t)(job + 1));     // code = job + 1; 0 ends a chain
+}
+
+// the owner's walk: the chain's (rank -> slot) pairs by ascending rank; calls f(rank, slot) for each
+template <typename F>
+__device__ __forceinline__ void msg_chain_in_rank_order(const int32_t *__restrict__ next, int64_t my_job, int cap, int nranks, F f) {
+  int lo = -1;                                               // ranks <= lo are done
+  for (int n = 0; n < nranks; ++n) {
+    int best_r = nranks, best_slot = 0;
+    for (int64_t c = my_job + 1; c != 0; c = next[c - 1]) {
+      const int rr = (int)((c - 1) / cap);
+      if (rr > lo && rr < best_r) { best_r = rr; best_slot = (int)((c - 1) - (int64_t)rr * cap); }
+    }
+    if (best_r == nranks) break;
+    f(best_r, best_slot);
+    lo = best_r;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_apply_user_msgs(const float *__restrict__ msgs, int nranks, size_t stride, int cap,
+                                                         int U, int k, int d, float *__restrict__ Gu, float *__restrict__ Tu,
+                                                         float scale, uint32_t *__restrict__ head,
+                                                         const int32_t *__restrict__ next) {
+  constexpr int G = 16;
+  const int64_t job = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  int r, slot, u;
+  if (!msg_job(msgs, nranks, stride, cap, U, job, r, slot, u)) return;
+  if (head[u] != (uint32_t)(job + 1)) return;                // another occurrence owns this user
+  const size_t hdr = msg_hdr(cap);
   float *pg = Gu + (size_t)u * k, *pt = d ? Tu + (size_t)u * d : nullptr;
-  for (int c = lane; c < k; c += G) pg[c] += scale * ig[c];
-  for (int c = lane; c < d; c += G) pt[c] += scale * it[c];
+  msg_chain_in_rank_order(next, job, cap, nranks, [&](int rr, int ss) {
+    const float *m = msgs + (size_t)rr * stride + hdr;
+    const float *ig = m + (size_t)ss * k, *it = m + (size_t)cap * k + (size_t)ss * d;
+    if (VEC) {
+      for (int c = lane * 4; c < k; c += G * 4) {
+        float4 p = ld4(pg + c); const float4 g = ld4(ig + c);
+        p.x += scale * g.x; p.y += scale * g.y; p.z += scale * g.z; p.w += scale * g.w;
+        *reinterpret_cast<float4 *>(pg + c) = p;
+      }
+      for (int c = lane * 4; c < d; c += G * 4) {
+        float4 p = ld4(pt + c); const float4 g = ld4(it + c);
+        p.x += scale * g.x; p.y += scale * g.y; p.z += scale * g.z; p.w += scale * g.w;
+        *reinterpret_cast<float4 *>(pt + c) = p;
+      }
+    } else {
+      for (int c = lane; c < k; c += G) pg[c] += scale * ig[c];
+      for (int c = lane; c < d; c += G) pt[c] += scale * it[c];
+    }
+  });
+  if (lane == 0) head[u] = 0u;
+}
+
+template <int G, bool VEC>
+__device__ __forceinline__ void row_accum(float *__restrict__ dst, const float *__restrict__ src, int n, int lane) {
+  if (VEC) {
+    for (int c = lane * 4; c < n; c += G * 4) {
+      float4 p = ld4(dst + c); const float4 g = ld4(src + c);
+      p.x += g.x; p.y += g.y; p.z += g.z; p.w += g.w;
+      *reinterpret_cast<float4 *>(dst + c) = p;
+    }
+  } else {
+    for (int c = lane; c < n; c += G) dst[c] += src[c];
+  }
 }
 
 // adam_tf23 in the replicated-user step: a user's gradient is the SUM over the ranks' rows (a user may sit in several
-// ranks' batches), so the rows are first added into the zeroed staging tables rank by rank (ids are distinct within a
-// message: plain read-modify-write, the same additions in the same order on every replica) ...
-__global__ __launch_bounds__(256) void k_accum_user_msg(const float *__restrict__ msg, int cap, int U, int k, int d,
-                                                        float *__restrict__ dGu, float *__restrict__ dTu,
-                                                        uint32_t *__restrict__ flagU) {
-  constexpr int G = 16;
-  const int slot = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) / G), lane = threadIdx.x % G;
-  int cnt = reinterpret_cast<const int32_t *>(msg)[0];
-  cnt = cnt < cap ? cnt : cap;
-  if (slot >= cnt) return;
-  const int u = reinterpret_cast<const int32_t *>(msg)[1 + slot];
-  if ((unsigned)u >= (unsigned)U) return;
-  const float *ig = msg + 1 + cap + (size_t)slot * k, *it = msg + 1 + cap + (size_t)cap * k + (size_t)slot * d;
-  float *pg = dGu + (size_t)u * k, *pt = d ? dTu + (size_t)u * d : nullptr;
-  for (int c = lane; c < k; c += G) pg[c] += ig[c];
-  for (int c = lane; c < d; c += G) pt[c] += it[c];
-  if (lane == 0) flagU[u] = 1u;
-}
-
-// ... and then every touched user takes ONE lazy-exact Adam step (replay of what the row missed, then step t): one lane
-// group per (rank, slot), the first to claim the user's flag does it.
+// ranks' batches): the owner of the user's chain (k_msg_link) adds the rows into the zeroed staging row by ascending
+// rank -- the same additions in the same order on every replica -- and then the user takes ONE lazy-exact Adam step
+// (replay of what the row missed, then step t; adam_apply_row re-zeroes the staging row).
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void k_adam_apply_msg_users(AdamTables T, AdamLazy a, const float *__restrict__ msgs, int nranks,
-                                                              size_t stride, int cap, float *dGu, float *dTu, uint32_t *flagU,
-                                                              int t, float lr_t) {
+                                                              size_t stride, int cap, float *dGu, float *dTu, uint32_t *head,
+                                                              const int32_t *__restrict__ next, int t, float lr_t) {
   const int64_t job = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
-  if (job >= (int64_t)nranks * cap) return;
-  const int r = (int)(job / cap), slot = (int)(job - (int64_t)r * cap);
-  const float *msg = msgs + (size_t)r * stride;
-  int cnt = reinterpret_cast<const int32_t *>(msg)[0];
-  cnt = cnt < cap ? cnt : cap;
-  if (slot >= cnt) return;
-  const int row = reinterpret_cast<const int32_t *>(msg)[1 + slot];
-  if ((unsigned)row >= (unsigned)T.U) return;
-  unsigned claimed = 0;
-  if (lane == 0) claimed = atomicExch(flagU + row, 0u);
-  claimed = __shfl(claimed, 0, G);
-  if (!claimed) return;
+  int r, slot, row;
+  if (!msg_job(msgs, nranks, stride, cap, T.U, job, r, slot, row)) return;
+  if (head[row] != (uint32_t)(job + 1)) return;
+  const size_t hdr = msg_hdr(cap);
+  float *gg = dGu + (size_t)row * T.k, *gt = T.d ? dTu + (size_t)row * T.d : nullptr;
+  msg_chain_in_rank_order(next, job, cap, nranks, [&](int rr, int ss) {
+    const float *m = msgs + (size_t)rr * stride + hdr;
+    const float *ig = m + (size_t)ss * T.k, *it = m + (size_t)cap * T.k + (size_t)ss * T.d;
+    row_accum<G, VEC>(gg, ig, T.k, lane);                  // lane -> element mapping of adam_apply_row: a lane reads back
+    if (T.d) row_accum<G, VEC>(gt, it, T.d, lane);          // only what it wrote itself
+  });
   const int from = T.lastU[row];
   if (from < t - 1) adam_replay_kind<G, VEC>(T, true, row, lane, from, t - 1, a);
-  adam_apply_row<G, VEC>(T.Gu + (size_t)row * T.k, T.mGu + (size_t)row * T.k, T.vGu + (size_t)row * T.k, dGu + (size_t)row * T.k, T.k, lane, t, lr_t, a);
-  if (T.d) adam_apply_row<G, VEC>(T.Tu + (size_t)row * T.d, T.mTu + (size_t)row * T.d, T.vTu + (size_t)row * T.d, dTu + (size_t)row * T.d, T.d, lane, t, lr_t, a);
-  if (lane == 0) T.lastU[row] = t;
+  adam_apply_row<G, VEC>(T.Gu + (size_t)row * T.k, T.mGu + (size_t)row * T.k, T.vGu + (size_t)row * T.k, gg, T.k, lane, t, lr_t, a);
+  if (T.d) adam_apply_row<G, VEC>(T.Tu + (size_t)row * T.d, T.mTu + (size_t)row * T.d, T.vTu + (size_t)row * T.d, gt, T.d, lane, t, lr_t, a);
+  if (lane == 0) { T.lastU[row] = t; head[row] = 0u; }
 }
 
 // dEp = sum over ranks (fixed order) of the dense parts of their messages
@@ -1374,57 +1464,98 @@ __global__ __launch_bounds__(256) void k_sum_dense_msgs(const float *__restrict_
 
 }  // namespace
 
+static inline size_t msg_rows_end(const bprx_handle *h, int64_t cap) {       // offset of the dense part
+  return msg_hdr(cap) + (size_t)cap * (size_t)(h->cfg.embed_k + h->cfg.embed_d);
+}
+
 extern "C" int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap) {
   if (!h || cap <= 0) return -1;
-  const int64_t k = h->cfg.embed_k, d = h->cfg.embed_d, D = h->cfg.feat_dim;
-  return 1 + cap + cap * (k + d) + ((h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : D * d + D);
+  const int64_t d = h->cfg.embed_d, D = h->cfg.feat_dim;
+  const int64_t n = (int64_t)msg_rows_end(h, cap) + ((h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : D * d + D);
+  return (n + 3) & ~(int64_t)3;
 }
 
 extern "C" int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream) {
   if (!h || !user || !msg || B <= 0 || cap <= 0) return BPRX_E_INVALID;
   if (!(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD)) BPRX_FAIL(h, BPRX_E_STATE, "pack_user_msg needs BPRX_FLAG_EXPORT_USER_GRAD");
+  if (!h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "pack_user_msg outside a step (after bprx_step_begin[_sparse])");
   hipStream_t s = (hipStream_t)stream;
   const int k = h->cfg.embed_k, d = h->cfg.embed_d;
-  BPRX_HIP(h, hipMemsetAsync(msg, 0, sizeof(float), s));                       // count
-  hipLaunchKernelGGL(k_pack_user_msg, dim3((unsigned)((B * 16 + 255) / 256)), dim3(256), 0, s, user, B, h->cfg.num_users, k, d,
-                     (int)cap, h->flagU, h->dGu, h->dTu, msg, h->errflag);
+  const dim3 grid((unsigned)((B + 255) / 256));
+  if (vec_ok(h) && ((uintptr_t)msg & 15) == 0)
+    hipLaunchKernelGGL(k_pack_user_msg<true>, grid, dim3(256), 0, s, user, B, h->cfg.num_users, k, d, (int)cap, h->flagU, h->dGu,
+                       h->dTu, msg, h->msg_cursor, h->errflag);
+  else
+    hipLaunchKernelGGL(k_pack_user_msg<false>, grid, dim3(256), 0, s, user, B, h->cfg.num_users, k, d, (int)cap, h->flagU, h->dGu,
+                       h->dTu, msg, h->msg_cursor, h->errflag);
   BPRX_LAUNCH_CHECK(h, "k_pack_user_msg");
   const size_t nd = (h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : (size_t)h->cfg.feat_dim * (d + 1);
-  if (nd) BPRX_HIP(h, hipMemcpyAsync(msg + 1 + cap + cap * (int64_t)(k + d), h->dEp, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (nd) {
+    if (h->pending_stage < 2) BPRX_FAIL(h, BPRX_E_STATE, "the message carries dE|dBp: pack it after bprx_step_begin[_dense]");
+    BPRX_HIP(h, hipMemcpyAsync(msg + msg_rows_end(h, cap), h->dEp, nd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   return BPRX_OK;
 }
 
 extern "C" int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t nranks, int64_t cap, float scale, void *stream) {
   if (!h || !msgs || nranks <= 0 || cap <= 0) return BPRX_E_INVALID;
   if (!h->bound) BPRX_FAIL(h, BPRX_E_STATE, "tables not bound");
+  if (!(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD)) BPRX_FAIL(h, BPRX_E_STATE, "apply_user_msgs needs BPRX_FLAG_EXPORT_USER_GRAD");
+  if ((int64_t)nranks * cap >= ((int64_t)1 << 31) - 1) BPRX_FAIL(h, BPRX_E_INVALID, "nranks * cap too large");
   hipStream_t s = (hipStream_t)stream;
   const int k = h->cfg.embed_k, d = h->cfg.embed_d;
   const size_t stride = (size_t)bprx_user_msg_floats(h, cap);
+  const size_t jobs = (size_t)nranks * (size_t)cap;
+  if (h->msg_next_n < jobs) {                                                  // first call (or a larger world / capacity)
+    BPRX_HIP(h, hipStreamSynchronize(s));
+    if (h->msg_next) (void)hipFree(h->msg_next);
+    h->msg_next = nullptr; h->msg_next_n = 0;
+    if (hipMalloc((void **)&h->msg_next, jobs * sizeof(int32_t)) != hipSuccess) {
+      (void)hipGetLastError();
+      BPRX_FAIL(h, BPRX_E_NOMEM, "apply_user_msgs: chain links (%zu entries)", jobs);
+    }
+    h->msg_next_n = jobs;
+  }
+  const bool vec = vec_ok(h) && ((uintptr_t)msgs & 15) == 0;
+  hipLaunchKernelGGL(k_msg_link, dim3((unsigned)((jobs + 255) / 256)), dim3(256), 0, s, msgs, (int)nranks, stride, (int)cap,
+                     h->cfg.num_users, h->flagU, h->msg_next);
   if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
-    // sum the ranks' rows per user (rank order), then one lazy-exact Adam step per touched user (`scale` is sgd's -lr)
-    for (int r = 0; r < nranks; ++r)
-      hipLaunchKernelGGL(k_accum_user_msg, dim3((unsigned)((cap * 16 + 255) / 256)), dim3(256), 0, s, msgs + (size_t)r * stride,
-                         (int)cap, h->cfg.num_users, k, d, h->dGu, h->dTu, h->flagU);
+    // per touched user: the ranks' rows summed in rank order, then one lazy-exact Adam step (`scale` is sgd's -lr)
     const float tt = (float)h->adam_t;
     const float lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, tt)) / (1.0f - powf(h->cfg.beta1, tt));
-    const bool vec = vec_ok(h);
     const int G = pick_group(k, d, vec);
     const AdamTables T = make_adam_tables(h);
     const AdamLazy al = {h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->lr_hist};
-    DISPATCH_G(G, vec, k_adam_apply_msg_users, grid_for((int64_t)nranks * cap, G), s, T, al, msgs, (int)nranks, stride, (int)cap,
-               h->dGu, h->dTu, h->flagU, (int)h->adam_t, lr_t);
-  } else
-  for (int r = 0; r < nranks; ++r)                                             // rank order: identical on every replica
-    hipLaunchKernelGGL(k_apply_user_msg, dim3((unsigned)((cap * 16 + 255) / 256)), dim3(256), 0, s, msgs + (size_t)r * stride,
-                       (int)cap, h->cfg.num_users, k, d, h->t.Gu, h->t.Tu, scale);
+    DISPATCH_G(G, vec, k_adam_apply_msg_users, grid_for((int64_t)jobs, G), s, T, al, msgs, (int)nranks, stride, (int)cap,
+               h->dGu, h->dTu, h->flagU, h->msg_next, (int)h->adam_t, lr_t);
+  } else if (vec) {
+    hipLaunchKernelGGL(k_apply_user_msgs<true>, grid_for((int64_t)jobs, 16), dim3(256), 0, s, msgs, (int)nranks, stride, (int)cap,
+                       h->cfg.num_users, k, d, h->t.Gu, h->t.Tu, scale, h->flagU, h->msg_next);
+  } else {
+    hipLaunchKernelGGL(k_apply_user_msgs<false>, grid_for((int64_t)jobs, 16), dim3(256), 0, s, msgs, (int)nranks, stride, (int)cap,
+                       h->cfg.num_users, k, d, h->t.Gu, h->t.Tu, scale, h->flagU, h->msg_next);
+  }
   const size_t nd = (h->cfg.flags & BPRX_FLAG_DENSE_ALLREDUCE) ? 0 : (size_t)h->cfg.feat_dim * (d + 1);
   if (nd) {
     unsigned blocks = (unsigned)((nd + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_sum_dense_msgs, dim3(blocks), dim3(256), 0, s, msgs, nranks, stride, (size_t)(1 + cap + cap * (int64_t)(k + d)),
-                       nd, h->dEp);
+    hipLaunchKernelGGL(k_sum_dense_msgs, dim3(blocks), dim3(256), 0, s, msgs, nranks, stride, msg_rows_end(h, cap), nd, h->dEp);
   }
-  BPRX_LAUNCH_CHECK(h, "k_apply_user_msg");
+  BPRX_LAUNCH_CHECK(h, "k_apply_user_msgs");
+  return BPRX_OK;
+}
+
+// bprx_dense_grad() = sum over ranks (rank order: bit-identical replicas) of `parts` = nranks dense gradients back to back
+// (an all-gather of bprx_dense_grad()), for handles created with BPRX_FLAG_DENSE_ALLREDUCE that prefer the ordered sum to
+// an RCCL all-reduce
+extern "C" int bprx_sum_dense_parts(bprx_handle *h, const float *parts, int32_t nranks, void *stream) {
+  if (!h || !parts || nranks <= 0) return BPRX_E_INVALID;
+  if (h->cfg.model != BPRX_MODEL_VBPR) BPRX_FAIL(h, BPRX_E_STATE, "sum_dense_parts: VBPR only");
+  const size_t nd = (size_t)h->cfg.feat_dim * (h->cfg.embed_d + 1);
+  unsigned blocks = (unsigned)((nd + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_sum_dense_msgs, dim3(blocks), dim3(256), 0, (hipStream_t)stream, parts, nranks, nd, (size_t)0, nd, h->dEp);
+  BPRX_LAUNCH_CHECK(h, "k_sum_dense_msgs");
   return BPRX_OK;
 }
 

@@ -236,38 +236,49 @@ class ItemShardedVBPR:
 class ReplicatedUserVBPR:
     """Item-sharded VBPR with REPLICATED user tables (SURVEY 8(e), C4 option "users replicated + sparse delta
     all-gather"): rank r owns an item shard (Gi, Bi, F never cross xGMI; negatives are local) and a full copy of Gu / Tu.
-    A step:  bprx_step_begin on the local batch (global user ids; user gradients are summed per user into the staging
-    tables instead of being applied) -> bprx_pack_user_msg: one fixed-size message per rank
-    [count | ids | dGu rows | dTu rows | dE|dBp] -> ONE all_gather_into_tensor -> bprx_apply_user_msgs: every replica adds
-    every rank's rows in rank order (bit-identical replicas) and sums the dE|dBp parts in rank order -> bprx_step_end.
+    A step:  bprx_step_begin_sparse on the local batch (global user ids; user gradients are summed per user into the
+    staging tables instead of being applied) -> bprx_pack_user_msg: one fixed-size message per rank
+    [count | ids | dGu rows | dTu rows] -> all_gather_into_tensor, asynchronous, beside bprx_step_begin_dense (item rows, W,
+    backward projection) -> the dense gradient's exchange (all-gather + ordered sum, or RCCL all-reduce) ->
+    bprx_apply_user_msgs: every replica adds every rank's rows per user in rank order (bit-identical replicas) ->
+    bprx_step_end.
     No data-dependent split sizes, hence no host synchronisation and no all-to-all; the message holds `user_cap` distinct
     users per batch (epoch-walk batches of B triplets touch about B / positives-per-user of them; more than user_cap is
     reported by sync_check()).  The global step equals the single-GPU batch-synchronous step on the concatenation of all
     ranks' batches (tests/test_gpu_dist.py)."""
 
     def __init__(self, rank, world, Gu, Tu, Gi_shard, Bi_shard, F_shard, E, Bp, lr, reg, max_batch, user_cap=None,
-                 feat_dtype="bf16", group=None, device=None, optimizer="sgd", dense_reduce="gather"):
+                 feat_dtype="bf16", group=None, device=None, optimizer="sgd", dense_reduce="gather", overlap=True):
         """optimizer: 'sgd' | 'adam_tf23' (lazy-exact: every replica sums the ranks' rows per user in rank order and takes
         the same Adam step, so the replicas stay bit-identical).
-        dense_reduce: 'gather' = dE|dBp travels inside the message and is summed in rank order (bit-identical replicas by
-        construction); 'allreduce' = a separate RCCL all-reduce(sum) of the dense gradient, the form north_star names --
-        (N-1)/N instead of N-1 message-sized transfers per rank for the dense part, one more collective per step."""
+        dense_reduce: 'gather' = the ranks' dE|dBp are all-gathered and summed in rank order (bit-identical replicas by
+        construction); 'allreduce' = an RCCL all-reduce(sum) of the dense gradient, the form north_star names --
+        (N-1)/N instead of N-1 message-sized transfers per rank for the dense part.
+        overlap: True = the step runs in two halves (bprx_step_begin_sparse / _dense): the user rows are packed and their
+        all-gather is started right after the per-triplet gradients, so it travels over xGMI WHILE item rows, W and the
+        backward projection dE|dBp = F^T W (about a third of the step) are computed; only the 1-MB dense exchange is
+        exposed.  False = the round-1 order: one message [user rows | dE|dBp] after the whole of bprx_step_begin."""
         from .engine import Engine
         self.rank, self.world, self.group, self.lr = rank, world, group, lr
-        self.dense_reduce = dense_reduce
+        self.dense_reduce, self.overlap = dense_reduce, bool(overlap)
+        if dense_reduce not in ("gather", "allreduce"):
+            raise ValueError("dense_reduce: 'gather' | 'allreduce'")
         k, d = Gu.shape[1], Tu.shape[1]
+        separate_dense = self.overlap or dense_reduce == "allreduce"      # the message carries the user rows only
         self.eng = Engine(model="vbpr", num_users=Gu.shape[0], num_items=Gi_shard.shape[0], embed_k=k, embed_d=d,
                           feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer=optimizer, lr=lr, reg=reg,
-                          max_batch=max_batch, device=device, export_user_grad=True,
-                          dense_allreduce=(dense_reduce == "allreduce"))
+                          max_batch=max_batch, device=device, export_user_grad=True, dense_allreduce=separate_dense)
         self.eng.bind(Gu=Gu, Gi=Gi_shard, Bi=Bi_shard, Tu=Tu, F=F_shard, E=E, Bp=Bp)
         dev = self.eng.device
-        self.dense = self.eng.dense_grad() if dense_reduce == "allreduce" else None
+        self.dense = self.eng.dense_grad() if separate_dense else None
         self.cap = int(user_cap if user_cap is not None else max_batch)
         n = self.eng.user_msg_floats(self.cap)
         self.msg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.msgs = torch.zeros(world * n, dtype=torch.float32, device=dev)
-        self.host_staged = world > 1 and dist.get_backend(group) != "nccl"     # gloo: test mode
+        self.dparts = (torch.zeros(world * self.dense.numel(), dtype=torch.float32, device=dev)
+                       if separate_dense and dense_reduce == "gather" else None)
+        self.live = dist.is_initialized()
+        self.host_staged = self.live and dist.get_backend(group) != "nccl"     # gloo: test mode
 
     @property
     def Gu(self):
@@ -277,27 +288,58 @@ class ReplicatedUserVBPR:
     def Tu(self):
         return self.eng.t["Tu"]
 
-    def step(self, u_global, i_local, j_local, want_loss=False):
-        self.eng.step_begin(u_global, i_local, j_local)
-        self.eng.pack_user_msg(u_global, self.cap, self.msg)
-        if self.dense is not None and self.world > 1:                  # dense_reduce == 'allreduce': RCCL sum of dE|dBp
-            if self.host_staged:
-                h = self.dense.cpu()
-                dist.all_reduce(h, group=self.group)
-                self.dense.copy_(h)
-            else:
-                dist.all_reduce(self.dense, group=self.group)
-        if self.world == 1 and not dist.is_initialized():
-            self.msgs.copy_(self.msg)
-        elif self.host_staged:
-            h = self.msg.cpu()
+    # -- collectives: RCCL (asynchronous: the returned work is waited for where the result is needed), or staged through
+    #    the host for the gloo test mode, or a plain copy without a process group
+    def _all_gather(self, out, inp):
+        if not self.live:
+            out.copy_(inp)
+            return None
+        if self.host_staged:
+            h = inp.cpu()
             parts = [torch.empty_like(h) for _ in range(self.world)]
             dist.all_gather(parts, h, group=self.group)
-            self.msgs.copy_(torch.cat(parts))
+            out.copy_(torch.cat(parts))
+            return None
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+
+    def _all_reduce(self, t):
+        if not self.live:
+            return None
+        if self.host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, group=self.group, async_op=True)
+
+    def step(self, u_global, i_local, j_local, want_loss=False):
+        eng = self.eng
+        if not self.overlap:
+            eng.step_begin(u_global, i_local, j_local)
+            eng.pack_user_msg(u_global, self.cap, self.msg)
+            wd = self._all_reduce(self.dense) if self.dense is not None and self.world > 1 else None
+            wm = self._all_gather(self.msgs, self.msg)
+            for w in (wd, wm):
+                if w is not None:
+                    w.wait()
+            eng.apply_user_msgs(self.msgs, self.world, self.cap, -self.lr)
+            return eng.step_end(want_loss=want_loss)
+        eng.step_begin_sparse(u_global, i_local, j_local)          # ... per-triplet gradients: user rows are final
+        eng.pack_user_msg(u_global, self.cap, self.msg)
+        wm = self._all_gather(self.msgs, self.msg)                  # in flight beside:
+        eng.step_begin_dense()                                      # item rows, W, dE|dBp = F^T W
+        if self.dense_reduce == "allreduce":
+            wd = self._all_reduce(self.dense) if self.world > 1 else None
         else:
-            dist.all_gather_into_tensor(self.msgs, self.msg, group=self.group)     # RCCL, the step's only collective
-        self.eng.apply_user_msgs(self.msgs, self.world, self.cap, -self.lr)
-        return self.eng.step_end(want_loss=want_loss)
+            wd = self._all_gather(self.dparts, self.dense)
+        if wm is not None:
+            wm.wait()
+        eng.apply_user_msgs(self.msgs, self.world, self.cap, -self.lr)
+        if wd is not None:
+            wd.wait()
+        if self.dense_reduce == "gather":
+            eng.sum_dense_parts(self.dparts, self.world)
+        return eng.step_end(want_loss=want_loss)
 
 
 RowExchange = UserRowExchange      # the routing is the same whichever table is the remote one

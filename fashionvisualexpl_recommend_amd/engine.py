@@ -159,6 +159,16 @@ class Engine:
     def step_begin(self, user, pos, neg):
         _ffi.check(self.h, self.lib.bprx_step_begin(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), _stream()))
 
+    def step_begin_sparse(self, user, pos, neg):
+        """First half of step_begin (the user-side gradients are final afterwards); the index tensors must stay alive and
+        unchanged until step_begin_dense has been called."""
+        self._pend_idx = (user, pos, neg)
+        _ffi.check(self.h, self.lib.bprx_step_begin_sparse(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), _stream()))
+
+    def step_begin_dense(self):
+        _ffi.check(self.h, self.lib.bprx_step_begin_dense(self.h, _stream()))
+        self._pend_idx = None
+
     def dense_grad(self):
         """fp32 view of the handle-owned dense gradient buffer [D*d + D] (dE then dBp) for the RCCL all-reduce."""
         p, n = C.c_void_p(), C.c_int64()
@@ -191,6 +201,9 @@ class Engine:
 
     def apply_user_msgs(self, msgs, nranks, cap, scale):
         _ffi.check(self.h, self.lib.bprx_apply_user_msgs(self.h, _ptr(msgs), int(nranks), int(cap), float(scale), _stream()))
+
+    def sum_dense_parts(self, parts, nranks):
+        _ffi.check(self.h, self.lib.bprx_sum_dense_parts(self.h, _ptr(parts), int(nranks), _stream()))
 
     def item_grad(self):
         """Zero-copy views [I,k], [I] of the staging tables that hold the exported item-row gradients."""

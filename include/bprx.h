@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BPRX_ABI_VERSION 4
+#define BPRX_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define BPRX_API __attribute__((visibility("default")))
@@ -146,6 +146,15 @@ BPRX_API int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t 
                     void *stream);
 BPRX_API int bprx_dense_grad(bprx_handle *h, float **ptr, int64_t *count);
 BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
+/* _begin itself in two halves (bprx_step_begin == _begin_sparse + _begin_dense), so that a collective on the user-side
+   gradients overlaps the backward projection:
+     _begin_sparse  index pass, item projections P = F.[E|Bp], per-triplet gradients: the USER-side gradients of the batch
+                    are final afterwards (bprx_user_grad / bprx_pack_user_msg may follow at once)
+     _begin_dense   item rows, W, dE|dBp = F^T W (bprx_dense_grad() is final afterwards); reads the index buffers of
+                    _begin_sparse again: they must stay valid and unchanged until it returns */
+BPRX_API int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
+                           void *stream);
+BPRX_API int bprx_step_begin_dense(bprx_handle *h, void *stream);
 
 /* Item-sharded multi-GPU helpers.
    bprx_step_project: the item-projection prologue of the step (P = F.[E|Bp]) on its own, so that it can overlap the
@@ -159,19 +168,25 @@ BPRX_API int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream);
 /* Replicated-user multi-GPU step (item-sharded VBPR with every rank holding ALL user rows; needs
    BPRX_FLAG_EXPORT_USER_GRAD and a handle created with num_users = the GLOBAL user count): ONE fixed-size all-gather per
    step, no data-dependent routing, no host synchronisation.
-     bprx_user_msg_floats   size (in 4-byte words) of one rank's message for `cap` distinct users per batch
-     bprx_pack_user_msg     after bprx_step_begin: moves the summed gradient rows of the batch's distinct users out of the
-                            staging tables (which are left all-zero) into msg = [count | ids[cap] | dGu[cap,k] |
-                            dTu[cap,d] | dE|dBp], more than `cap` distinct users are reported by bprx_sync_check
-                            (BPRX_E_RANGE)
+     bprx_user_msg_floats   size (in 4-byte words, a multiple of 4) of one rank's message for `cap` distinct users per batch
+     bprx_pack_user_msg     after bprx_step_begin (without the dense part, BPRX_FLAG_DENSE_ALLREDUCE: already after
+                            bprx_step_begin_sparse): moves the summed gradient rows of the batch's distinct users out of the
+                            staging tables (which are left all-zero) into msg = [count,0,0,0 | ids[cap rounded up to 4] |
+                            dGu[cap,k] | dTu[cap,d] | dE|dBp]; more than `cap` distinct users are reported by
+                            bprx_sync_check (BPRX_E_RANGE).  msg should be 16-byte aligned (vector copies).
      bprx_apply_user_msgs   after the all-gather (msgs = nranks messages back to back): Gu/Tu[id] += scale * row for
-                            every rank's rows, rank by rank in rank order (within a rank ids are distinct: plain
-                            read-modify-write, so every replica performs the same additions in the same order and the
-                            replicas stay bit-identical), and bprx_dense_grad() = sum over ranks of their dE|dBp parts in
-                            rank order; then bprx_step_end. */
+                            every rank's rows, per user in ascending rank order (the occurrences of a user across the
+                            messages are chained and one lane group applies them one after the other: every replica
+                            performs the same additions in the same order and the replicas stay bit-identical; two
+                            launches whatever nranks is), and bprx_dense_grad() = sum over ranks of their dE|dBp parts in
+                            rank order; then bprx_step_end.
+     bprx_sum_dense_parts   BPRX_FLAG_DENSE_ALLREDUCE handles that want the ORDERED sum instead of an RCCL all-reduce:
+                            parts = an all-gather of bprx_dense_grad() (nranks x count floats); bprx_dense_grad() becomes
+                            their sum in rank order. */
 BPRX_API int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap);
 BPRX_API int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream);
 BPRX_API int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t nranks, int64_t cap, float scale, void *stream);
+BPRX_API int bprx_sum_dense_parts(bprx_handle *h, const float *parts, int32_t nranks, void *stream);
 BPRX_API int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi);
 BPRX_API int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, void *stream);
 BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,

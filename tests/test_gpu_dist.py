@@ -127,7 +127,7 @@ def test_user_sharded_bprmf_two_ranks_match_oracle():
     mp.spawn(_worker_bprmf, args=(2, _free_port()), nprocs=2, join=True)
 
 
-def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather"):
+def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather", overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -149,7 +149,7 @@ def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather
         c = lambda a: torch.as_tensor(a.copy())
         m = ReplicatedUserVBPR(rank, world, c(t["Gu"]), c(t["Tu"]), c(t["Gi"][it]), c(t["Bi"][it]), c(t["F"][it]), c(t["E"]),
                                c(t["Bp"]), lr, reg, max_batch=B, user_cap=U, feat_dtype=dtype, device=0, optimizer=opt,
-                               dense_reduce=dense_reduce)
+                               dense_reduce=dense_reduce, overlap=overlap)
         o = orc.OracleModel(**t, quant=1 if dtype == "bf16" else 0)
         for step in range(4 if opt != "sgd" else 3):
             batches = []
@@ -203,6 +203,50 @@ def test_replicated_user_vbpr_two_ranks_adam_tf23_match_oracle():
 def test_replicated_user_vbpr_dense_allreduce_form():
     """dense_reduce='allreduce': dE|dBp leaves the message and is summed by a collective all-reduce (north_star's form)."""
     mp.spawn(_worker_replicated, args=(2, _free_port(), "fp32", "sgd", "allreduce"), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("opt,dense_reduce", [("sgd", "gather"), ("adam_tf23", "gather"), ("sgd", "allreduce")])
+def test_replicated_user_vbpr_single_message_order(opt, dense_reduce):
+    """overlap=False: the round-1 order (the whole of bprx_step_begin, then ONE message [user rows | dE|dBp])."""
+    mp.spawn(_worker_replicated, args=(2, _free_port(), "fp32", opt, dense_reduce, False), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam_tf23"])
+def test_replicated_single_rank_equals_plain_step(opt):
+    """One rank, no process group: pack (many workgroups, duplicate users, one cursor atomic per workgroup) -> chain ->
+    apply must give the plain single-GPU step."""
+    from fashionvisualexpl_recommend_amd import synth
+    from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    rs = np.random.RandomState(11)
+    U, I, k, d, D, B = 3000, 700, 16, 12, 128, 5000
+    F = synth.make_features(I, D, seed=3)
+    F = (F / np.abs(F).max()).astype(np.float32)
+    t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k), Bi=(rs.standard_normal(I) * 0.01).astype(np.float32),
+             Tu=synth.glorot_uniform(rs, U, d), F=F, E=synth.glorot_uniform(rs, D, d), Bp=synth.glorot_uniform(rs, D, 1).reshape(-1))
+    c = lambda a: torch.as_tensor(a.copy())
+    lr, reg = (0.05, 1e-3) if opt == "sgd" else (0.01, 1e-3)
+    m = ReplicatedUserVBPR(0, 1, c(t["Gu"]), c(t["Tu"]), c(t["Gi"]), c(t["Bi"]), c(t["F"]), c(t["E"]), c(t["Bp"]), lr, reg,
+                           max_batch=B, user_cap=U, feat_dtype="fp32", device=0, optimizer=opt)
+    e = Engine(model="vbpr", num_users=U, num_items=I, embed_k=k, embed_d=d, feat_dim=D, feat_dtype="fp32", optimizer=opt, lr=lr,
+               reg=reg, max_batch=B, device=0).bind(**{n: c(v) for n, v in t.items()})
+    for step in range(3):
+        br = np.random.RandomState(40 + step)
+        nb = B - 37 * step
+        u = torch.as_tensor(br.randint(U if step != 1 else 50, size=nb).astype(np.int32), device="cuda")   # step 1: hot users
+        i = torch.as_tensor(br.randint(I, size=nb).astype(np.int32), device="cuda")
+        j = torch.as_tensor(br.randint(I, size=nb).astype(np.int32), device="cuda")
+        m.step(u, i, j)
+        e.step(u, i, j)
+    m.eng.sync_check()
+    e.sync_check()
+    # adam: a step is lr * m / (sqrt(v) + eps) -- for an element whose summed gradient is ~eps the two paths' different
+    # summation orders (staging atomics) move the step by a visible fraction of lr (3 of 48 000 elements here)
+    at = 2e-6 if opt == "sgd" else 2e-2 * lr
+    for n in ("Gu", "Tu", "Gi", "Bi", "E", "Bp"):
+        np.testing.assert_allclose(m.eng.t[n].cpu().numpy(), e.t[n].cpu().numpy(), rtol=2e-5, atol=at, err_msg=n)
+    g, tt = m.eng.user_grad()
+    assert float(g.abs().max()) == 0.0 and float(tt.abs().max()) == 0.0
 
 
 def test_replicated_user_message_overflow_is_reported():

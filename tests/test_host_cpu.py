@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _ffi.lib().bprx_abi_version() == _ffi.ABI_VERSION == 4
+    assert _ffi.lib().bprx_abi_version() == _ffi.ABI_VERSION == 5
 
 
 def test_create_rejects_bad_config_without_gpu_work():
