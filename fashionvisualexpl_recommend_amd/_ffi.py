@@ -90,6 +90,7 @@ def lib():
         "bprx_topk": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
         "bprx_sync_check": (C.c_int, [vp, vp]),
         "bprx_probe_stream_read": (i64, [vp, i64, vp, vp]),
+        "bprx_probe_row_gather": (i64, [vp, i64, i32, vp, i64, i32, vp, vp]),
         "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
         "bprx_profile_read": (C.c_int, [vp, vp, vp]),
         "bprx_sample_philox": (C.c_int, [vp, vp, vp, i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp, vp, vp]),
@@ -116,7 +117,7 @@ EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
-           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_profile_enable",
+           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_row_gather", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",
            "bprx_apply_user_msgs", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]

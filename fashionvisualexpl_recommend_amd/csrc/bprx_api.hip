@@ -208,11 +208,15 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     delete h;
     return BPRX_E_HIP;
   }
-  // Measured (C2): running the sparse optimizer pass beside the backward projection is SLOWER (0.385 vs 0.363 ms/step;
-  // both are bandwidth-bound and interfere: proj_bwd 93 -> 144 us, apply 35 -> 64 us).  Off unless BPRX_SIDE_STREAM=1.
+  // BPRX_SIDE_STREAM (bit mask).  Measured on C2:
+  //   1  the sparse optimizer pass beside the backward projection: SLOWER (0.385 vs 0.363 ms/step; both are
+  //      bandwidth-bound and interfere: proj_bwd 93 -> 144 us, apply 35 -> 64 us)
+  //   2  the index pass beside the forward projection: no gain (0.2599 vs 0.2600; row_count 13.9 -> 24.9 us, proj_fwd +7 us)
+  //   4  lazy Adam's catch-up (ALU-bound: correctly rounded sqrt / divide per replayed element and step) beside the
+  //      HBM-bound forward projection of a streaming step: adam_tf23 0.330 -> 0.317 ms/step.  The default with adam_tf23.
   {
     const char *e = getenv("BPRX_SIDE_STREAM");
-    h->side_mode = e ? atoi(e) : 0;
+    h->side_mode = e ? atoi(e) : ((vb && cfg->optimizer == BPRX_OPT_ADAM_TF23 && h->adam_lazy) ? 4 : 0);
     if (!h->side_mode) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
   }
   {
@@ -354,7 +358,12 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
   if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  // list mode: both projections over the batch's distinct items only (needs the index pass BEFORE the forward projection)
+  h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
+  h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
+  h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
   float lr_t = h->cfg.lr;
+  bool catchup_aside = false;     // BPRX_SIDE_STREAM & 4: the (ALU-bound) lazy-Adam catch-up runs beside the (HBM-bound) projection
   if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
     h->adam_t += 1;
     float t = (float)h->adam_t;
@@ -363,18 +372,16 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
       // the ring holds lr_s of the last ADAM_HIST steps: before it would wrap, everything is caught up (amortised: one
       // sweep per ~8000 steps); then the rows of THIS batch are brought to step t-1 for the forward pass
       if (h->adam_t - h->adam_synced >= bprx_adam_hist() - 2 && (rc = bprx_launch_adam_sync(h, h->adam_t - 1, s))) return rc;
-      if ((rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, s))) return rc;
+      catchup_aside = vb && !h->proj_fresh && !h->list_mode && !h->p_valid && h->side && (h->side_mode & 4);
+      if (!catchup_aside && (rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, s))) return rc;
     }
   }
-  // list mode: both projections over the batch's distinct items only (needs the index pass BEFORE the forward projection)
-  h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
-  h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
-  h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
-  const bool fork_index = vb && !h->list_mode && !h->proj_fresh && h->side && h->side_mode == 2;
-  if (fork_index) {                                        // index pass (no dependence on P) beside the projection
+  const bool fork_index = vb && !h->list_mode && !h->proj_fresh && h->side && (h->side_mode & 2);
+  if (fork_index || catchup_aside) {                       // work that does not depend on P, beside the projection
     BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
     BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    if ((rc = bprx_launch_index_pass(h, user, pos, neg, B, h->side))) return rc;
+    if (catchup_aside && (rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, h->side))) return rc;
+    if (fork_index && (rc = bprx_launch_index_pass(h, user, pos, neg, B, h->side))) return rc;
     BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
   }
   if (h->list_mode) {
@@ -389,8 +396,8 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
     if (!h->p_valid && (rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;  // every item
   }
   h->proj_fresh = false;
-  if (fork_index) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
-  else if (!h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
+  if (fork_index || catchup_aside) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
+  if (!fork_index && !h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   h->pending_B = B;
   h->pending_stage = 1;
@@ -410,7 +417,7 @@ extern "C" int bprx_step_begin_dense(bprx_handle *h, void *stream) {
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, lr_t, s))) return rc;                  // item rows + W, no float atomics
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
   // projection -- with VBPR it runs on the side stream beside it
-  if (vb && h->side && h->side_mode == 1) {
+  if (vb && h->side && (h->side_mode & 1)) {
     BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
     BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     if ((rc = bprx_launch_apply(h, user, pos, neg, B, lr_t, h->side))) return rc;

@@ -238,6 +238,11 @@ BPRX_API int bprx_topk(bprx_handle *h, int32_t u0, int32_t u1, float *scores, co
    sink: >= 8 KiB of device scratch).  Returns the number of bytes the launch reads, or a negative BPRX_E_* code.  Timed by
    the caller on `stream`: the rate this device's HBM delivers to a streaming kernel, quoted beside the 8 TB/s spec. */
 BPRX_API int64_t bprx_probe_stream_read(const void *buf, int64_t bytes, void *sink, void *stream);
+/* Measurement helper: n lane groups each move one row of table[num_rows][row_floats] (fp32, row_floats a multiple of 4)
+   picked by idx[] -- mode 0: read; mode 1: read and write back in place (idx distinct).  The access shape of the sparse
+   kernels (a table row per index): the rate quoted beside their gather/scatter roofline.  Returns the bytes moved. */
+BPRX_API int64_t bprx_probe_row_gather(void *table, int64_t num_rows, int32_t row_floats, const int32_t *idx, int64_t n,
+                                       int32_t mode, void *sink, void *stream);
 
 /* Synchronise `stream` and report deferred device-side errors (index out of range). */
 BPRX_API int bprx_sync_check(bprx_handle *h, void *stream);

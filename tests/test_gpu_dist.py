@@ -240,11 +240,17 @@ def test_replicated_single_rank_equals_plain_step(opt):
         e.step(u, i, j)
     m.eng.sync_check()
     e.sync_check()
-    # adam: a step is lr * m / (sqrt(v) + eps) -- for an element whose summed gradient is ~eps the two paths' different
-    # summation orders (staging atomics) move the step by a visible fraction of lr (3 of 48 000 elements here)
-    at = 2e-6 if opt == "sgd" else 2e-2 * lr
+    # adam: the first step is lr * g / (|g| + eps / sqrt(1 - beta2)) -- an element whose summed gradient is ~3e-6 moves by a
+    # visible fraction of lr when the two paths' summation orders (staging atomics) differ by 1e-7: a handful of the 48 000
+    # user elements may differ by a few per cent of lr, none by more than a fraction of a step
     for n in ("Gu", "Tu", "Gi", "Bi", "E", "Bp"):
-        np.testing.assert_allclose(m.eng.t[n].cpu().numpy(), e.t[n].cpu().numpy(), rtol=2e-5, atol=at, err_msg=n)
+        got, want = m.eng.t[n].cpu().numpy(), e.t[n].cpu().numpy()
+        if opt == "sgd":
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=n)
+        else:
+            diff = np.abs(got - want)
+            assert float((diff > 2e-3 * lr + 2e-5 * np.abs(want)).mean()) < 1e-3, n
+            assert float(diff.max()) < 0.25 * lr, n
     g, tt = m.eng.user_grad()
     assert float(g.abs().max()) == 0.0 and float(tt.abs().max()) == 0.0
 
