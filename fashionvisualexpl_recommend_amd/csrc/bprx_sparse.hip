@@ -44,6 +44,7 @@ struct SparseArgs {
   // pass then walks this list instead of every occurrence of the batch
   int32_t *slist, *slist_n;
   int use_list;
+  int wg_combine;            // user-row gradients of a workgroup-wide user meet in LDS (BPRX_WG_COMBINE=0: wave-level only)
   int reg_items;             // exclusive item rows stored from the forward pass's registers (G >= 32, BPRMF)
 };
 
@@ -261,9 +262,18 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   // meet at barriers (user-row combination below); in a partial workgroup the surplus groups leave here
   const bool full = ((int64_t)(blockIdx.x + 1) * 256) / G <= B;
   if (b >= B) return;
-  const int u = clamp_idx(user[b], a.U, a.errflag, 1);
-  const int i = clamp_idx(pos[b], a.I, a.errflag, 2), j = clamp_idx(neg[b], a.I, a.errflag, 3);
+  // (the three index loads are issued before the first is looked at: clamp_idx's error store would otherwise order them
+  //  one behind the other -- three memory round trips instead of one at the head of every wave)
+  const int u_raw = user[b], i_raw = pos[b], j_raw = neg[b];
+  const int u = clamp_idx(u_raw, a.U, a.errflag, 1);
+  const int i = clamp_idx(i_raw, a.I, a.errflag, 2), j = clamp_idx(j_raw, a.I, a.errflag, 3);
   const int k = a.k, d = a.d;
+  // ... and everything that depends on the indices alone is requested together with the rows, not after them
+  const float bi = a.Bi[i], bj = a.Bi[j];
+  int mulU = 0, mulI = 0, mulJ = 0;                       // (ONE uniform branch: a load under a branch of its own is waited for on the spot)
+  if (a.fastU | a.fastI) { mulU = a.cntU[u]; mulI = a.cntI[i]; mulJ = a.cntI[j]; }
+  int rkI = 0, rkJ = 0, spI = 0, spJ = 0;
+  if (!a.item_atomics) { rkI = a.seg_rank[b]; rkJ = a.seg_rank[B + b]; spI = a.seg_ptr[i]; spJ = a.seg_ptr[j]; }
   const float *gu = a.Gu + (size_t)u * k, *gi = a.Gi + (size_t)i * k, *gj = a.Gi + (size_t)j * k;
   const float *tu = d ? a.Tu + (size_t)u * d : nullptr;
   const float *Pi = d ? a.P + (size_t)i * a.PS : nullptr, *Pj = d ? a.P + (size_t)j * a.PS : nullptr;
@@ -305,7 +315,6 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
     }
   }
   si = group_sum<G>(si); sj = group_sum<G>(sj); nrm = group_sum<G>(nrm);
-  const float bi = a.Bi[i], bj = a.Bi[j];
   float xp = bi + si, xn = bj + sj;
   if (d) {
     ti = group_sum<G>(ti); tj = group_sum<G>(tj);
@@ -320,15 +329,10 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   const float g = inr ? -1.0f / (1.0f + expf(diff)) : 0.f;            // -sigmoid(-diff)
   const float reg = a.reg, r2 = 2.f * reg, lr = a.lr;
   // exclusive rows: nobody else reads or writes them in this batch, so the in-place update is batch-synchronous
-  const bool exU = a.fastU && a.cntU[u] == 1;
-  const bool exI = a.fastI && a.cntI[i] == 1, exJ = a.fastI && a.cntI[j] == 1;    // i == j gives count 2: shared
-  // item side: global atomics, or (segments) one 8-byte entry per occurrence
-  bool iaI = true, iaJ = true;
-  int rkI = 0, rkJ = 0;
-  if (!a.item_atomics) {                                   // every occurrence writes its entry; hot items are chunked later
-    rkI = a.seg_rank[b]; rkJ = a.seg_rank[B + b];
-    iaI = false; iaJ = false;
-  }
+  const bool exU = a.fastU && mulU == 1;
+  const bool exI = a.fastI && mulI == 1, exJ = a.fastI && mulJ == 1;               // i == j gives count 2: shared
+  // item side: global atomics, or (segments) one 8-byte entry per occurrence (hot items are chunked later)
+  const bool iaI = a.item_atomics, iaJ = a.item_atomics;
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
     if (a.use_list) {
@@ -338,21 +342,21 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
       if (iaI) {
         if (exI) { a.wBi[i] = bi - lr * (g + r2 * bi); a.cntI[i] = 0; }
         else atomicAdd(a.dBi + i, g + r2 * bi);
-      } else a.seg_ent[a.seg_ptr[i] + rkI] = make_int2(u, __float_as_int(g));
+      } else a.seg_ent[spI + rkI] = make_int2(u, __float_as_int(g));
       if (iaJ) {
         if (exJ) { a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj); a.cntI[j] = 0; }
         else atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
-      } else a.seg_ent[a.seg_ptr[j] + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
+      } else a.seg_ent[spJ + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
     } else {
     if (!exU) a.flagU[u] = 1u;
     if (iaI) {
       if (exI) a.wBi[i] = bi - lr * (g + r2 * bi);
       else { atomicAdd(a.dBi + i, g + r2 * bi); a.flagI[i] = 1u; }
-    } else a.seg_ent[a.seg_ptr[i] + rkI] = make_int2(u, __float_as_int(g));
+    } else a.seg_ent[spI + rkI] = make_int2(u, __float_as_int(g));
     if (iaJ) {
       if (exJ) a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj);
       else { atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj); a.flagI[j] = 1u; }
-    } else a.seg_ent[a.seg_ptr[j] + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
+    } else a.seg_ent[spJ + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
     }
   }
   // ---- backward: per-occurrence gradients from the same pre-update rows (L1/L2 hits) ----
@@ -378,7 +382,7 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   __shared__ __attribute__((aligned(16))) float s_du[4][WGROW];
   bool wgc = false;
   const int wv = threadIdx.x >> 6;
-  if (full && k + d <= WGROW) {
+  if (full && k + d <= WGROW && a.wg_combine) {
     const int u0 = __shfl(u, 0, 64);
     const bool wave_ok = G == 64 ? !exU : comb;
     if ((threadIdx.x & 63) == 0) s_u[wv] = wave_ok ? u0 : -1 - wv;
@@ -1029,8 +1033,9 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   const int lane = threadIdx.x % G;
   if (job >= 2 * B) return;
   const int rk = a.seg_rank[job];
+  const int item_raw = job < B ? pos[job] : neg[job - B];            // (requested together with the rank, not after it)
   if (rk % SEG_CAP != 0) return;                 // chunk leaders only: rank 0 owns an ordinary item, ranks 0, CAP, 2 CAP, ...
-  const int item = clamp_quiet(job < B ? pos[job] : neg[job - B], a.I);       // share a hot one
+  const int item = clamp_quiet(item_raw, a.I);                       // share a hot one
   const int n = a.cntI[item];
   const int ns = n - rk < SEG_CAP ? n - rk : SEG_CAP;
   const int2 *ent = a.seg_ent + a.seg_ptr[item] + rk;
@@ -1048,6 +1053,10 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   const float mk = hk ? 1.f : 0.f, md = hd ? 1.f : 0.f;
   const float *TuS = d ? a.Tu : a.Gu;                                 // d == 0: any valid address, md == 0
   const int ds = d ? d : k;
+  // the item's own row and bias depend on `item` alone: requested now, beside the first entries, not after the loop
+  const size_t og = (size_t)item * k + c4, ow = (size_t)item * a.PS;
+  float4 q = ld4(Gi + (size_t)item * k + ck);
+  const float pb = Bi[item];
   for (; e + 2 <= ns; e += 2) {                                       // two entries in flight
     const int2 r0 = ent[e], r1 = ent[e + 1];
     const int u0 = r0.x & 0x7fffffff, u1 = r1.x & 0x7fffffff;
@@ -1075,13 +1084,8 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   }
   const float r2 = 2.f * a.reg;
   const float fn = (float)ns, fj = (float)nj, fi = (float)(ns - nj);
-  const size_t og = (size_t)item * k + c4, ow = (size_t)item * a.PS;
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f), gr = q;
-  if (hk) {
-    q = ld4(Gi + og);
-    gr = make_float4(ag.x + r2 * fn * q.x, ag.y + r2 * fn * q.y, ag.z + r2 * fn * q.z, ag.w + r2 * fn * q.w);
-  }
-  const float pb = Bi[item];
+  float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (hk) gr = make_float4(ag.x + r2 * fn * q.x, ag.y + r2 * fn * q.y, ag.z + r2 * fn * q.z, ag.w + r2 * fn * q.w);
   float gb = gsum + r2 * fi * pb + (r2 * 0.1f) * fj * pb;
   float wl = gsum;                                                    // column d of W: the Bp column of [theta_u | 1]
   if (n > SEG_CAP) {
@@ -1187,6 +1191,8 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.use_list = (h->slist && a.fastU && a.fastI && !h->graph_mode) ? 1 : 0;
   static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
   a.reg_items = reg_items_env;
+  static const int wg_combine_env = getenv("BPRX_WG_COMBINE") ? atoi(getenv("BPRX_WG_COMBINE")) : 1;
+  a.wg_combine = wg_combine_env;
   a.slist = h->slist;
   a.slist_n = h->slist ? h->slist_n + h->slist_slot : nullptr;
   return a;
