@@ -21,7 +21,21 @@ static hipError_t dalloc_zero(T **p, size_t n) {
 }
 
 static void graph_drop(bprx_handle *h) {
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  for (int q = 0; q < h->graph_n; ++q)
+    if (h->graph_ents[q].exec) (void)hipGraphExecDestroy(h->graph_ents[q].exec);
+  h->graph_n = 0;
+}
+
+static bprx_handle::GraphSig graph_sig(const bprx_handle *h) {
+  return {h->list_slot, h->slist_slot, h->qs_slot, h->et_valid, h->p_valid, h->absmax_valid, h->W_dirty};
+}
+static void graph_sig_apply(bprx_handle *h, const bprx_handle::GraphSig &g) {
+  h->list_slot = g.list_slot; h->slist_slot = g.slist_slot; h->qs_slot = g.qs_slot;
+  h->et_valid = g.et_valid; h->p_valid = g.p_valid; h->absmax_valid = g.absmax_valid; h->W_dirty = g.W_dirty;
+}
+static bool graph_sig_eq(const bprx_handle::GraphSig &a, const bprx_handle::GraphSig &b) {
+  return a.list_slot == b.list_slot && a.slist_slot == b.slist_slot && a.qs_slot == b.qs_slot && a.et_valid == b.et_valid &&
+         a.p_valid == b.p_valid && a.absmax_valid == b.absmax_valid && a.W_dirty == b.W_dirty;
 }
 
 static void free_scratch(bprx_handle *h) {
@@ -223,11 +237,14 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     hipDeviceProp_t prop;
     h->num_cu = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  // Measured on C2 (ROCm 7.0, bench.py on a non-default stream): replaying the step as a hipGraph is SLOWER than the
-  // eleven plain launches it replaces (0.2828 vs 0.2747 ms/step, identical results) -- the host is not the limiter
-  // and the graph launch itself costs more than the dispatch gaps it removes.  Opt-in: BPRX_GRAPH=1.
+  // Measured (ROCm 7.0, bench.py on a non-default stream): replaying the step as a hipGraph is SLOWER than the plain
+  // launches it replaces, for large batches (C2, B = 65 536: 0.2828 vs 0.2747 ms/step) and for small ones alike (C2 tables,
+  // B = 256: 0.0576 vs 0.0529; B = 4096: 0.0944 vs 0.0906; BPRMF B = 256: 0.0256 vs 0.0261 ms/step) -- the host is not the
+  // limiter: a small step is six dependent kernels of 5-10 us each (chains of 3-5 memory round trips), and a graph
+  // launch costs more than the dispatch gaps it removes.  Off by default.  BPRX_GRAPH=1: always; 2: steps of B <= 8192.
   h->graph_mode = 0;
-  if (const char *e = getenv("BPRX_GRAPH")) h->graph_mode = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("BPRX_GRAPH")) h->graph_mode = atoi(e);
+  if (h->graph_mode < 0 || h->graph_mode > 2) h->graph_mode = 0;
   h->prof_pending = new std::vector<bprx_handle::ProfRec>();
   h->prof_free = new std::vector<hipEvent_t>();
   *out = h;
@@ -523,56 +540,54 @@ static int step_plain(bprx_handle *h, const int32_t *user, const int32_t *pos, c
 extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
                          float *loss_out, void *stream) {
   if (!h) return BPRX_E_INVALID;
-  // (BPRX_GRAPH=1) The sgd step is a fixed sequence of ~11 launches whose arguments repeat from call to call (index
-  // buffers, loss scalar, stream): it can be captured into a hipGraph once and replayed -- one launch per step.  Not for adam (lr_t changes every step), not while per-kernel profiling is
-  // on, not on the legacy default stream (cannot be captured): those take the plain path.
-  // Nor with fp8 features (the [E|Bp] absmax slot alternates on the host: a replayed graph would reuse one slot and never
-  // clear it).  The captured sequence is made self-contained: the derived images count as stale at capture time.
-  const bool can_graph = h->graph_mode && h->cfg.optimizer == BPRX_OPT_SGD && !h->prof && stream != nullptr && !h->side &&
-                         h->bound && B > 0 && B <= h->cfg.max_batch && user && pos && neg && !h->proj_fresh && !h->pending_B &&
-                         h->cfg.feat_dtype != BPRX_F_FP8 &&
-                         (h->list_policy == 0 || (h->list_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));   // list cursors alternate on the host
+  // The sgd step is a fixed sequence of launches whose arguments repeat from call to call (index buffers, loss scalar,
+  // stream): captured into a hipGraph and replayed, it is ONE launch per step (see graph_mode in bprx_internal.h for
+  // when that pays).  Not for adam (lr_t changes every step), not while per-kernel profiling is on, not on the legacy
+  // default stream (cannot be captured): those take the plain path.
+  const bool can_graph = (h->graph_mode == 1 || (h->graph_mode == 2 && B <= 8192)) && h->cfg.optimizer == BPRX_OPT_SGD &&
+                         !h->prof && stream != nullptr && !h->side && h->bound && B > 0 && B <= h->cfg.max_batch && user && pos &&
+                         neg && !h->proj_fresh && !h->pending_B;
   if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
   hipStream_t s = (hipStream_t)stream;
-  const bool same = h->graph_exec && h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg &&
-                    h->graph_key.loss == loss_out && h->graph_key.B == B && h->graph_key.stream == stream &&
-                    h->graph_key.lr == h->cfg.lr && h->graph_key.reg == h->cfg.reg;
+  const bool same = h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg && h->graph_key.loss == loss_out &&
+                    h->graph_key.B == B && h->graph_key.stream == stream && h->graph_key.lr == h->cfg.lr &&
+                    h->graph_key.reg == h->cfg.reg;
   if (!same) {
-    graph_drop(h);
     // capture only when a call repeats the previous call's arguments (a caller that walks through a pre-generated
     // stream passes new pointers every step and must not pay for a capture each time)
-    const bool repeat = h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg && h->graph_key.loss == loss_out &&
-                        h->graph_key.B == B && h->graph_key.stream == stream && h->graph_key.lr == h->cfg.lr &&
-                        h->graph_key.reg == h->cfg.reg;
+    graph_drop(h);
     h->graph_key.u = user; h->graph_key.i = pos; h->graph_key.j = neg; h->graph_key.loss = loss_out; h->graph_key.B = B;
     h->graph_key.stream = stream; h->graph_key.lr = h->cfg.lr; h->graph_key.reg = h->cfg.reg;
-    if (!repeat) return step_plain(h, user, pos, neg, B, loss_out, stream);
-    h->et_valid = h->p_valid = false;                         // the graph refreshes Et and P itself on every replay
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      h->graph_mode = 0;                                      // this stream cannot be captured: plain launches from now on
-      return step_plain(h, user, pos, neg, B, loss_out, stream);
-    }
-    const int rc = step_plain(h, user, pos, neg, B, loss_out, stream);
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(s, &g);
-    if (rc || e != hipSuccess || !g) {
-      if (g) (void)hipGraphDestroy(g);
-      (void)hipGetLastError();
-      h->graph_mode = 0;
-      return rc ? rc : step_plain(h, user, pos, neg, B, loss_out, stream);
-    }
-    const hipError_t ei = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (ei != hipSuccess) {
-      h->graph_exec = nullptr;
-      h->graph_mode = 0;
-      return step_plain(h, user, pos, neg, B, loss_out, stream);
-    }
-    h->graph_key.u = user; h->graph_key.i = pos; h->graph_key.j = neg; h->graph_key.loss = loss_out; h->graph_key.B = B;
-    h->graph_key.stream = stream; h->graph_key.lr = h->cfg.lr; h->graph_key.reg = h->cfg.reg;
+    return step_plain(h, user, pos, neg, B, loss_out, stream);
   }
-  BPRX_HIP(h, hipGraphLaunch(h->graph_exec, s));
+  const bprx_handle::GraphSig in = graph_sig(h);
+  for (int q = 0; q < h->graph_n; ++q)
+    if (graph_sig_eq(h->graph_ents[q].in, in)) {
+      BPRX_HIP(h, hipGraphLaunch(h->graph_ents[q].exec, s));
+      graph_sig_apply(h, h->graph_ents[q].out);              // what the launches of the captured step left on the host
+      return BPRX_OK;
+    }
+  if (h->graph_n == 4) graph_drop(h);                        // the host state wandered (outside reads between steps): start over
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    h->graph_mode = 0;                                       // this stream cannot be captured: plain launches from now on
+    return step_plain(h, user, pos, neg, B, loss_out, stream);
+  }
+  const int rc = step_plain(h, user, pos, neg, B, loss_out, stream);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &g);
+  hipGraphExec_t exec = nullptr;
+  const bool ok = !rc && e == hipSuccess && g && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess && exec;
+  if (g) (void)hipGraphDestroy(g);
+  if (!ok) {
+    (void)hipGetLastError();
+    h->graph_mode = 0;
+    h->pending_B = 0;
+    graph_sig_apply(h, in);                                  // nothing ran: back to the state before the capture
+    return rc ? rc : step_plain(h, user, pos, neg, B, loss_out, stream);
+  }
+  h->graph_ents[h->graph_n++] = {exec, in, graph_sig(h)};
+  BPRX_HIP(h, hipGraphLaunch(exec, s));
   return BPRX_OK;
 }
 

@@ -92,8 +92,15 @@ struct bprx_handle {
   bool side_pending;
   int side_mode;                  // BPRX_SIDE_STREAM: 1 = sparse optimizer pass beside proj_bwd, 2 = index pass beside proj_fwd
   // hipGraph of the whole sgd step (bprx_step): captured on first use, replayed while the call's arguments repeat
-  int graph_mode;                 // env BPRX_GRAPH (default 0: measured slower than plain launches); 1 = capture + replay
-  hipGraphExec_t graph_exec;
+  // hipGraphs of the whole sgd step (bprx_step): captured when a call repeats the previous call's arguments, replayed while
+  // they keep repeating.  A captured launch sequence depends on the host-side state below (cursor slots that alternate from
+  // step to step, validity of the derived images), so an exec is stored with the state it was captured in and the state
+  // it leaves, and is replayed only from the same state; a steady training loop alternates between two execs.
+  int graph_mode;                 // env BPRX_GRAPH: 0 (default) = never, 1 = always, 2 = small steps only (B <= 8192)
+  struct GraphSig { int list_slot, slist_slot, qs_slot; bool et_valid, p_valid, absmax_valid, W_dirty; };
+  struct GraphEnt { hipGraphExec_t exec; GraphSig in, out; };
+  GraphEnt graph_ents[4];
+  int graph_n;
   struct { const void *u, *i, *j, *loss; int64_t B; void *stream; float lr, reg; } graph_key;
   // per-kernel HIP-event timing (bprx_profile_*)
   bool prof;

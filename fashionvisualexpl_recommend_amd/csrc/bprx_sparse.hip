@@ -1188,7 +1188,7 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   }
   a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
   // shared-row list: both sides on the exclusive-row fast path (sgd, atomic staging, no exported gradients)
-  a.use_list = (h->slist && a.fastU && a.fastI && !h->graph_mode) ? 1 : 0;
+  a.use_list = (h->slist && a.fastU && a.fastI) ? 1 : 0;
   static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
   a.reg_items = reg_items_env;
   static const int wg_combine_env = getenv("BPRX_WG_COMBINE") ? atoi(getenv("BPRX_WG_COMBINE")) : 1;
