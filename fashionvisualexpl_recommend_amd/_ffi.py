@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbprx.so")
+LIB_PATH = os.environ.get("BPRX_LIB") or os.path.join(HERE, "libbprx.so")    # BPRX_LIB: A/B builds (scripts/)
 ABI_VERSION = 5
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2

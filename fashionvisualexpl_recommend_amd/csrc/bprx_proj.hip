@@ -36,6 +36,17 @@ __device__ __forceinline__ uint32_t f2e4m3(float x) {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 typedef __attribute__((ext_vector_type(2))) long i64x2_t;
+// A bf16 feature table is streamed once per projection (C2: 410 MB per pass, more than the 256-MiB Infinity Cache holds):
+// its loads carry the `nt` bit (streaming, no-retain), so that a pass does not push the step's RE-USED tables (P, the
+// factor tables, W: ~100 MB at C2) out of the Infinity Cache -- C2 0.2596 -> 0.2438 ms/step (proj_fwd 83.0 -> 76.8,
+// proj_bwd 72.6 -> 69.4, triplet_grad 38.1 -> 35.2 us), c4 shard 0.3561 -> 0.3503.  NOT for fp8 tables: C2's and C5's fp8
+// table (205 MB) fits the cache and the backward pass re-reads what the forward pass left there (c2fp8 with nt: 0.2091 ->
+// 0.2152 ms/step), nor in the v8 / f8s forward kernels (measured slower with it: c4 shard 118.8 -> 121.6, c5 74.2 -> 79.2 us).
+template <bool NT>
+__device__ __forceinline__ i32x4_t ld_stream16(const void *p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const i32x4_t *>(p));
+  else return *reinterpret_cast<const i32x4_t *>(p);
+}
 // one 16-byte operand fragment per lane: 8 bf16 (one 16x16x32 MFMA) or 16 fp8 (two 16x16x32 fp8 MFMAs over the low and
 // the high 8 bytes; A and B fragments are cut the same way, so every k is paired with itself exactly once)
 template <bool F8>
@@ -572,7 +583,8 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
                                                        (size_t)(pp & 15) * 8);                                           \
       } else {                                                                                                           \
         const size_t bidx = (size_t)((t0 >> 5) + blk / CBK) * (Deq >> 7) + (m0q >> 7) + blk % CBK;                       \
-        freg[ST][x] = *reinterpret_cast<const uint4 *>(F + bidx * 4096 + (size_t)(pp & 511) * 8);                        \
+        { const i32x4_t v_ = ld_stream16<!F8>(F + bidx * 4096 + (size_t)(pp & 511) * 8);                                 \
+          freg[ST][x] = make_uint4((unsigned)v_.x, (unsigned)v_.y, (unsigned)v_.z, (unsigned)v_.w); }                      \
       }                                                                                                                  \
     }                                                                                                                    \
     _Pragma("unroll") for (int x = 0; x < WPT; ++x) {                                                                    \
@@ -1137,7 +1149,7 @@ __device__ __forceinline__ void v10_body(const uint16_t *const (&asrc)[2], const
     int ce_ = (c_) + cshift;                                                                                          \
     if (ce_ >= nch) ce_ -= nch;                                                                                       \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int x = 0; x < 4; ++x)                   \
-        AR[mt][x] = *reinterpret_cast<const i32x4_t *>(asrc[mt] + ((size_t)ce_ << 12) + x * 512 + lane * 8);          \
+        AR[mt][x] = ld_stream16<!F8>(asrc[mt] + ((size_t)ce_ << 12) + x * 512 + lane * 8);                          \
     const uint16_t *bc_ = Et + (size_t)ce_ * et_chunk;                                                                \
     _Pragma("unroll") for (int x = 0; x < NBR; ++x) {                                                                 \
       int pc = tid + x * bdim;                                                                                        \
@@ -1595,11 +1607,11 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
     }
   }
   if constexpr (NT <= 9) {
-    // v10 (A through a wave-private LDS image, contiguous loads): the default for bf16 tables up to six column tiles --
-    // C2: 76.7-80.2 us against v8's 83.4-87.2 us on the same boxes (5.3-5.6 TB/s); not for fp8 tables (c2fp8: 45.0 vs
-    // 41.7 us) nor wider projections (c4 shard, nine tiles: 117.9 vs 110.7 us).  BPRX_FWD_LDS=0 keeps v8; variant 6 / 14
-    // forces v10 (+ staggered chunk order: 78.0 vs 76.7 us).
-    const bool lds_default = v == 4 && !f8 && NT <= 6 && !(getenv("BPRX_FWD_LDS") && atoi(getenv("BPRX_FWD_LDS")) == 0);
+    // v10 (A through a wave-private LDS image, contiguous loads, `nt`): the default for bf16 tables up to nine column tiles
+    // -- C2: 76.7-80.2 us against v8's 83.4-87.2 us on the same boxes; with streaming (`nt`) loads 76.8-77.2 us and the
+    // whole step 0.2596 -> 0.2436 ms; c4 shard (nine tiles): 116.5 us against v8's 118.8-125.7 us, step 0.3587 -> 0.3511.
+    // Not for fp8 tables (c2fp8: 45.0 vs 41.7 us).  BPRX_FWD_LDS=0 keeps v8; variant 6 / 14 forces v10 (+ staggered chunks).
+    const bool lds_default = v == 4 && !f8 && NT <= 9 && !(getenv("BPRX_FWD_LDS") && atoi(getenv("BPRX_FWD_LDS")) == 0);
     const int stg10 = v == 6 ? (stg & 1) : 0;
     if ((v == 6 || lds_default) && Deq % 256 == 0 && !rows) {
       constexpr int NWMAX = 8, NWMIN = 5;
