@@ -40,7 +40,7 @@ static bool graph_sig_eq(const bprx_handle::GraphSig &a, const bprx_handle::Grap
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -164,7 +164,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (h->seg_policy && vb && cfg->feat_dtype != BPRX_F_FP32 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
     if (h->seg_policy) {
       bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_ptr, I) == hipSuccess &&
-                 dalloc_zero(&h->seg_cursor, (size_t)1) == hipSuccess && dalloc_zero(&h->hot_done, I) == hipSuccess &&
+                 dalloc_zero(&h->seg_cursor, (size_t)2) == hipSuccess && dalloc_zero(&h->seg_lead, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->hot_done, I) == hipSuccess &&
                  dalloc_zero((int2 **)&h->seg_ent, (size_t)2 * MB) == hipSuccess;
       if (!ok2) {
         snprintf(g_create_err, sizeof(g_create_err), "segment scratch allocation failed");

@@ -58,7 +58,8 @@ struct bprx_handle {
                                   //    float atomics into the staging tables + claim-apply
   int32_t *seg_rank;              // [2 * max_batch] rank of occurrence (role*B + b) among its item's occurrences
   int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent (valid for items of the current batch)
-  int32_t *seg_cursor;            // [1] bump allocator of segments
+  int32_t *seg_cursor;            // [2] bump allocator of segments; number of chunk leaders listed in seg_lead
+  int32_t *seg_lead;              // [2 * max_batch] occurrences (role*B + b) that lead a chunk: k_item_seg's work list
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
   // touched-item list (sparse batches, 2B < I): both projections run over the batch's DISTINCT items only

@@ -36,6 +36,7 @@ struct SparseArgs {
   int fastU, fastI;               // per side: off for rows whose gradients are exported (staging rows)
   float lr;
   // occurrence segments (item_atomics == 0)
+  const int32_t *seg_lead, *seg_nlead;   // chunk leaders (occurrence numbers) and their count
   const int32_t *seg_rank;   // [2B] rank of occurrence (role*B + b) within its item
   const int32_t *seg_ptr;    // [I]  first entry of the item's segment
   int2 *seg_ent;             // [2B] {user | role << 31, g_b}
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
                                                    int32_t *__restrict__ slist, int32_t *__restrict__ slist_n, int slist_cap) {
   // housekeeping that would otherwise be two hipMemsetAsync launches (5-6 us each on the trace): the segment cursor, and
   // the bf16 W image of the previous step (consumed by its backward projection), re-zeroed for k_item_seg
-  if (seg_cursor && blockIdx.x == 0 && threadIdx.x == 0) *seg_cursor = 0;
+  if (seg_cursor && blockIdx.x == 0 && threadIdx.x == 0) { seg_cursor[0] = 0; seg_cursor[1] = 0; }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nzero16; e += (size_t)gridDim.x * 256)
     zero16[e] = make_uint4(0, 0, 0, 0);
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -222,15 +223,18 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
 __global__ __launch_bounds__(1024) void k_seg_alloc(const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
                                                     int64_t B, int I, const int32_t *__restrict__ rank,
                                                     const int32_t *__restrict__ cntI, int32_t *__restrict__ seg_ptr,
-                                                    int32_t *__restrict__ cursor) {
-  __shared__ int wsum[16];
-  __shared__ int wbase;
+                                                    int32_t *__restrict__ cursor, int32_t *__restrict__ lead) {
+  __shared__ int wsum[16], lsum[16];
+  __shared__ int wbase, lbase;
   const int64_t job = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int item = 0, c = 0;
+  bool leads = false;                            // this occurrence leads a chunk of its item's segment (rank 0, CAP, 2 CAP, ...)
   if (job < 2 * B) {
     item = clamp_quiet(job < B ? pos[job] : neg[job - B], I);
-    if (rank[job] == 0) c = cntI[item];
+    const int rk = rank[job];
+    if (rk == 0) c = cntI[item];
+    leads = rk % SEG_CAP == 0;
   }
   int incl = c;
 #pragma unroll
@@ -238,15 +242,21 @@ __global__ __launch_bounds__(1024) void k_seg_alloc(const int32_t *__restrict__ 
     const int v = __shfl_up(incl, o, 64);
     if (lane >= o) incl += v;
   }
+  const unsigned long long lb = __ballot(leads);
   if (lane == 63) wsum[w] = incl;
+  if (lane == 0) lsum[w] = __popcll(lb);
   __syncthreads();
   if (threadIdx.x == 0) {
-    int t = 0;
-    for (int q = 0; q < 16; ++q) { const int v = wsum[q]; wsum[q] = t; t += v; }
+    int t = 0, l = 0;
+    for (int q = 0; q < 16; ++q) { const int v = wsum[q]; wsum[q] = t; t += v; const int lv = lsum[q]; lsum[q] = l; l += lv; }
     wbase = t ? atomicAdd(cursor, t) : 0;
+    lbase = l ? atomicAdd(cursor + 1, l) : 0;
   }
   __syncthreads();
   if (c) seg_ptr[item] = wbase + wsum[w] + incl - c;
+  // the chunk leaders, compacted: k_item_seg runs one lane group per listed occurrence instead of one per occurrence with
+  // two thirds of the groups leaving at once (C2: 46 K leaders of 131 K occurrences)
+  if (leads) lead[lbase + lsum[w] + __popcll(lb & ((1ull << lane) - 1ull))] = (int32_t)job;
 }
 
 // One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
@@ -1029,13 +1039,19 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
                                                   float *__restrict__ Wf, uint16_t *__restrict__ Wb,
                                                   const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B,
                                                   float lr, AdamFuse af) {
-  const int64_t job = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
-  if (job >= 2 * B) return;
+  // one lane group per chunk leader (k_seg_alloc's list): rank 0 owns an ordinary item, ranks 0, CAP, 2 CAP, ... share a
+  // hot one.  (BPRX_SEG_LEAD=0: one group per occurrence, the non-leaders leave)
+  int64_t job = e0;
+  if (a.seg_nlead) {
+    if (e0 >= a.seg_nlead[0]) return;
+    job = a.seg_lead[e0];
+  } else if (job >= 2 * B) return;
   const int rk = a.seg_rank[job];
   const int item_raw = job < B ? pos[job] : neg[job - B];            // (requested together with the rank, not after it)
-  if (rk % SEG_CAP != 0) return;                 // chunk leaders only: rank 0 owns an ordinary item, ranks 0, CAP, 2 CAP, ...
-  const int item = clamp_quiet(item_raw, a.I);                       // share a hot one
+  if (rk % SEG_CAP != 0) return;
+  const int item = clamp_quiet(item_raw, a.I);
   const int n = a.cntI[item];
   const int ns = n - rk < SEG_CAP ? n - rk : SEG_CAP;
   const int2 *ent = a.seg_ent + a.seg_ptr[item] + rk;
@@ -1187,6 +1203,8 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
     a.fastI = 0; a.fastU = 0; a.fast = 0;
   }
   a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
+  static const int seg_lead_env = getenv("BPRX_SEG_LEAD") ? atoi(getenv("BPRX_SEG_LEAD")) : 1;
+  a.seg_lead = h->seg_lead; a.seg_nlead = (h->seg_cursor && seg_lead_env) ? h->seg_cursor + 1 : nullptr;
   // shared-row list: both sides on the exclusive-row fast path (sgd, atomic staging, no exported gradients)
   a.use_list = (h->slist && a.fastU && a.fastI) ? 1 : 0;
   static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
@@ -1593,7 +1611,7 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
   if (h->item_mode) {
     BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
     hipLaunchKernelGGL(k_seg_alloc, dim3((unsigned)((2 * B + 1023) / 1024)), dim3(1024), 0, s, i, j, B, a.I, h->seg_rank, h->cntI,
-                       h->seg_ptr, h->seg_cursor);
+                       h->seg_ptr, h->seg_cursor, h->seg_lead);
   }
   BPRX_LAUNCH_CHECK(h, "k_row_count/k_seg_alloc");
   return BPRX_OK;
