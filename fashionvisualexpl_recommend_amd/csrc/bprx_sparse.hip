@@ -156,8 +156,12 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
     bool ai = false, aj = false, su = false, si = false, sj = false;
     if (valid) {
       int ou = -1, oi = -1, oj = -1;
-      if (doU) { if (slist) ou = atomicAdd(cntU + u, 1); else atomicAdd(cntU + u, 1); }
-      if (doI) { oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1); }     // i == j: the second add returns one more
+      if (doU && doI) {                          // (one block: behind a branch of its own each atomic is waited for on the spot)
+        ou = atomicAdd(cntU + u, 1); oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1);
+      } else {
+        if (doU) ou = atomicAdd(cntU + u, 1);
+        if (doI) { oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1); }   // i == j: the second add returns one more
+      }
       ai = ilist && oi == 0; aj = ilist && oj == 0;
       su = slist && ou == 1; si = slist && oi == 1; sj = slist && oj == 1;
     }
@@ -208,8 +212,17 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
     slot_j = sl; loc_j = atomicAdd(&hcnt[sl], 1);
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < HS; t += 256)
-    if (hkey[t] >= 0) hbase[t] = atomicAdd(cntI + hkey[t], hcnt[t]);
+  {
+    // one returning atomic per distinct item of the workgroup: the (up to) four of a thread are all requested before the
+    // first result is stored (one after the other they were four memory round trips)
+    int hk[HS / 256], hb[HS / 256];
+#pragma unroll
+    for (int q = 0; q < HS / 256; ++q) hk[q] = hkey[threadIdx.x + q * 256];
+#pragma unroll
+    for (int q = 0; q < HS / 256; ++q) hb[q] = hk[q] >= 0 ? atomicAdd(cntI + hk[q], hcnt[threadIdx.x + q * 256]) : 0;
+#pragma unroll
+    for (int q = 0; q < HS / 256; ++q) hbase[threadIdx.x + q * 256] = hb[q];
+  }
   __syncthreads();
   if (valid) {
     rank[b] = hbase[slot_i] + loc_i;
