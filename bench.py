@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--no-dist-overlap", action="store_true",
                     help="N > 1, replicated mode: the round-1 order (ONE message [user rows | dE|dBp] after the whole local "
                          "step) instead of the user rows' all-gather travelling beside the backward projection")
+    ap.add_argument("--no-index-lookahead", action="store_true",
+                    help="draw each batch inside its own step (default: the NEXT step's batch is drawn at the start of a step "
+                         "and announced with bprx_hint_next_batch, so that its index pass runs on a side stream beside the "
+                         "running step's per-triplet kernels; still exactly one batch drawn and one step taken per timed step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-overlap", action="store_true",
                     help="draw each batch one step ahead on a side stream (measured on C2: 0.287 vs 0.280 ms/step without "
@@ -254,7 +258,28 @@ def main():
 
         prefetch(0)
 
+    # Default: one batch of look-ahead IN the stream -- step s first draws the batch of step s+1 into the other buffer set and
+    # names it to the library (bprx_hint_next_batch), then runs on its own batch.
+    from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR as _Rep
+    look = (batches is None and not pipe and not args.no_index_lookahead and (sharded is None or isinstance(sharded, _Rep)))
+    if look:
+        lbufs = (bufs, tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3)))
+        lstate = {"n": 0}
+
     def one_step(s):
+        if look:
+            slot = lstate["n"] & 1
+            if lstate["n"] == 0:
+                sampler.sample(B, out=lbufs[0])               # priming: the very first batch
+            lstate["n"] += 1
+            sampler.sample(B, out=lbufs[slot ^ 1])            # the NEXT step's batch
+            eng.hint_next_batch(*lbufs[slot ^ 1])
+            u, i, j = lbufs[slot]
+            if sharded is None:
+                eng.step(u, i, j, want_loss=False)
+            else:
+                sharded.step(u, i, j)
+            return
         if pipe:
             slot = state["n"] & 1
             state["n"] += 1
@@ -299,10 +324,11 @@ def main():
     eng.sync_check()
 
     # what this device's HBM delivers to a plain streaming-read kernel (bprx_probe_stream_read), on the launch stream
-    measured_peak = None
+    measured_peak = measured_peak_nt = None
     if rank == 0:
         try:
             measured_peak = hbm_stream_probe(torch, device, run_stream)
+            measured_peak_nt = hbm_stream_probe(torch, device, run_stream, nt=True)
         except Exception as e:                                # never let the probe take the bench line down
             print("hbm probe failed: %r" % (e,), file=sys.stderr)
 
@@ -314,7 +340,9 @@ def main():
     prof = eng.profile_read()
     eng.profile(False)
     torch.cuda.synchronize()
-    ub, ib, jb = sampler.sample(B, out=bufs) if batches is None else batches[0]
+    # (fresh buffers: the look-ahead sets may hold a batch whose index pass has already run)
+    ub, ib, jb = (sampler.sample(B, out=tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3)))
+                  if batches is None else batches[0])
     loss = float((eng.step(ub, ib, jb) if sharded is None else sharded.step(ub, ib, jb, want_loss=True)).item())
     assert np.isfinite(loss), loss
 
@@ -355,7 +383,10 @@ def main():
                   "avg_ms": kernels[dom]["avg_ms"],
                   # the same achieved rate against what a plain streaming-read kernel reaches on THIS device, measured
                   # in this run (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-                  "measured_peak": measured_peak, "frac_of_measured": (ach / measured_peak) if measured_peak else None}
+                  "measured_peak": measured_peak, "frac_of_measured": (ach / measured_peak) if measured_peak else None,
+                  # the same streaming-read kernel with `nt` loads (the policy of the bf16 feature passes): the higher ceiling
+                  "measured_peak_nt": measured_peak_nt,
+                  "frac_of_measured_nt": (ach / measured_peak_nt) if measured_peak_nt else None}
             # MFMA utilisation of the two projections (north_star: "MFMA utilisation on the projection against gfx950
             # peak"): flops EXECUTED per launch (2*I*D*PS each, padded columns included) / HIP-event duration / dense peak
             # (2.5 PF bf16; fp8 features: the forward uses the fp8 MFMA -> 5 PF, the backward widens F to bf16 -> 2.5 PF);
@@ -388,7 +419,9 @@ def main():
                        "sampler": (("device philox, uniform positive + rejection negative" if args.sampler == "philox" else
                                     "device epoch walk (every positive once per epoch, user-grouped) + philox negative")
                                    + ", one batch per step inside the timed region%s (%d positives/user)"
-                                   % (", drawn one step ahead on a side stream" if pipe else "", args.pos_per_user)
+                                   % (", drawn one step ahead on a side stream" if pipe else
+                                      (", drawn one step ahead in the stream and announced (bprx_hint_next_batch)" if look else ""),
+                                      args.pos_per_user)
                                    + (", Zipf(%.2f) item popularity" % args.zipf if args.zipf > 0 else ""))
                        if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,
@@ -405,8 +438,8 @@ def main():
         dist.destroy_process_group()
 
 
-def hbm_stream_probe(torch, device, stream):
-    """GB/s of bprx_probe_stream_read over a 1-GiB buffer (far larger than the 256-MiB Infinity Cache), best of 5 timed
+def hbm_stream_probe(torch, device, stream, nt=False):
+    """GB/s of bprx_probe_stream_read (nt: bprx_probe_stream_read_nt) over a 1-GiB buffer (far larger than the 256-MiB Infinity Cache), best of 5 timed
     launches after 2 warm-ups, timed with events on the launch stream."""
     import ctypes as C
     from fashionvisualexpl_recommend_amd import _ffi
@@ -420,7 +453,8 @@ def hbm_stream_probe(torch, device, stream):
         for it in range(7):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-            got = L.bprx_probe_stream_read(C.c_void_p(buf.data_ptr()), nbytes, C.c_void_p(sink.data_ptr()), sp)
+            got = (L.bprx_probe_stream_read_nt if nt else L.bprx_probe_stream_read)(C.c_void_p(buf.data_ptr()), nbytes,
+                                                                                    C.c_void_p(sink.data_ptr()), sp)
             b.record(stream)
             b.synchronize()
             if got < 0:

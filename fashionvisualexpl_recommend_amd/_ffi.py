@@ -77,6 +77,7 @@ def lib():
         "bprx_step_begin": (C.c_int, [vp, vp, vp, vp, i64, vp]),
         "bprx_step_begin_sparse": (C.c_int, [vp, vp, vp, vp, i64, vp]),
         "bprx_step_begin_dense": (C.c_int, [vp, vp]),
+        "bprx_hint_next_batch": (C.c_int, [vp, vp, vp, vp, i64]),
         "bprx_dense_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "bprx_step_end": (C.c_int, [vp, vp, vp]),
         "bprx_step_project": (C.c_int, [vp, vp]),
@@ -90,6 +91,7 @@ def lib():
         "bprx_topk": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
         "bprx_sync_check": (C.c_int, [vp, vp]),
         "bprx_probe_stream_read": (i64, [vp, i64, vp, vp]),
+        "bprx_probe_stream_read_nt": (i64, [vp, i64, vp, vp]),
         "bprx_probe_row_gather": (i64, [vp, i64, i32, vp, i64, i32, vp, vp]),
         "bprx_profile_enable": (C.c_int, [vp, C.c_int]),
         "bprx_profile_read": (C.c_int, [vp, vp, vp]),
@@ -115,9 +117,9 @@ def lib():
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
-           "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
+           "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts", "bprx_hint_next_batch",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
-           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_row_gather", "bprx_profile_enable",
+           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",
            "bprx_apply_user_msgs", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]

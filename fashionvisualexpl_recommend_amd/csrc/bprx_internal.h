@@ -60,6 +60,15 @@ struct bprx_handle {
   int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent (valid for items of the current batch)
   int32_t *seg_cursor;            // [2] bump allocator of segments; number of chunk leaders listed in seg_lead
   int32_t *seg_lead;              // [2 * max_batch] occurrences (role*B + b) that lead a chunk: k_item_seg's work list
+  // Second set of the index-pass state (segment mode): bprx_hint_next_batch names the NEXT step's index buffers and the
+  // running step launches that batch's index pass (k_row_count + k_seg_alloc: latency-bound, 21 us at C2) on the side stream
+  // beside its own latency-bound kernels, into this set; the next step swaps the sets instead of running the pass.
+  struct IdxAlt { int32_t *cntI, *seg_rank, *seg_ptr, *seg_cursor, *seg_lead; } alt;
+  const int32_t *hint_u, *hint_i, *hint_j; int64_t hint_B;          // bprx_hint_next_batch (consumed by the next step)
+  const int32_t *pf_u, *pf_i, *pf_j; int64_t pf_B; bool pf_done;    // index pass of that batch in flight / finished in `alt`
+  bool pf_launching;              // bprx_launch_index_pass runs for the prefetched batch (no W-image zeroing there)
+  bool pf_zero_w;                 // this step's k_dense_update re-zeroes the bf16 W image (the prefetched pass could not)
+  hipEvent_t ev_pf_fork, ev_pf_done;
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
   // touched-item list (sparse batches, 2B < I): both projections run over the batch's DISTINCT items only

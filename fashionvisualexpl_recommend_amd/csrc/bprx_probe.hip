@@ -6,15 +6,17 @@
 
 namespace {
 constexpr int PU = 8;
-__global__ __launch_bounds__(1024) void k_probe_stream(const uint4 *__restrict__ p, size_t per_wg, uint4 *__restrict__ sink) {
-  const uint4 *base = p + (size_t)blockIdx.x * per_wg;
-  uint4 acc = make_uint4(0, 0, 0, 0);
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <bool NT>
+__global__ __launch_bounds__(1024) void k_probe_stream(const u32x4_t *__restrict__ p, size_t per_wg, u32x4_t *__restrict__ sink) {
+  const u32x4_t *base = p + (size_t)blockIdx.x * per_wg;
+  u32x4_t acc = {0, 0, 0, 0};
   for (size_t i = threadIdx.x; i + (size_t)(PU - 1) * 1024 < per_wg; i += (size_t)PU * 1024) {
-    uint4 v[PU];
+    u32x4_t v[PU];
 #pragma unroll
-    for (int u = 0; u < PU; ++u) v[u] = base[i + (size_t)u * 1024];
+    for (int u = 0; u < PU; ++u) v[u] = NT ? __builtin_nontemporal_load(base + i + (size_t)u * 1024) : base[i + (size_t)u * 1024];
 #pragma unroll
-    for (int u = 0; u < PU; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+    for (int u = 0; u < PU; ++u) acc ^= v[u];
   }
   // keeps the loads alive; one 16-byte store per workgroup at most
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && threadIdx.x == 0) sink[blockIdx.x] = acc;
@@ -60,10 +62,19 @@ extern "C" int64_t bprx_probe_row_gather(void *table, int64_t num_rows, int32_t 
   return n * (int64_t)row_floats * 4 * (mode ? 2 : 1);     // bytes moved
 }
 
-extern "C" int64_t bprx_probe_stream_read(const void *buf, int64_t bytes, void *sink, void *stream) {
+static int64_t probe_stream(const void *buf, int64_t bytes, void *sink, void *stream, bool nt) {
   if (!buf || !sink || bytes < (int64_t)512 * PU * 1024 * 16) return BPRX_E_INVALID;
   const size_t per_wg = (size_t)bytes / 16 / 512 / ((size_t)PU * 1024) * ((size_t)PU * 1024);   // whole trips only
-  hipLaunchKernelGGL(k_probe_stream, dim3(512), dim3(1024), 0, (hipStream_t)stream, (const uint4 *)buf, per_wg, (uint4 *)sink);
+  if (nt) hipLaunchKernelGGL(k_probe_stream<true>, dim3(512), dim3(1024), 0, (hipStream_t)stream, (const u32x4_t *)buf, per_wg, (u32x4_t *)sink);
+  else hipLaunchKernelGGL(k_probe_stream<false>, dim3(512), dim3(1024), 0, (hipStream_t)stream, (const u32x4_t *)buf, per_wg, (u32x4_t *)sink);
   if (hipGetLastError() != hipSuccess) return BPRX_E_HIP;
   return (int64_t)(per_wg * 16 * 512);                    // bytes actually read
+}
+
+extern "C" int64_t bprx_probe_stream_read(const void *buf, int64_t bytes, void *sink, void *stream) {
+  return probe_stream(buf, bytes, sink, stream, false);
+}
+// the same with `nt` (streaming, no-retain) loads: what the bf16 feature passes use (Infinity Cache policy)
+extern "C" int64_t bprx_probe_stream_read_nt(const void *buf, int64_t bytes, void *sink, void *stream) {
+  return probe_stream(buf, bytes, sink, stream, true);
 }

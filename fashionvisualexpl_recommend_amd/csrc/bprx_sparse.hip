@@ -888,9 +888,14 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
                                                       uint16_t *__restrict__ EtF, const int32_t *__restrict__ ilist,
                                                       const int32_t *__restrict__ ilist_n, int32_t *__restrict__ ilist_n_next,
                                                       int bound, float *__restrict__ W, int32_t *__restrict__ cnt_reset,
-                                                      uint32_t *__restrict__ absmax_out) {
+                                                      uint32_t *__restrict__ absmax_out, uint4 *__restrict__ zero16,
+                                                      size_t nzero16) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[DU_KB][288];   // PS <= 272
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  // the bf16 W image, consumed by this step's backward projection, back to zero for the next step's k_item_seg (when that
+  // step's index pass -- which does it otherwise -- has already run: bprx_hint_next_batch)
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nzero16; e += (size_t)gridDim.x * 256)
+    zero16[e] = make_uint4(0, 0, 0, 0);
   if (ilist_n_next && blockIdx.x == 0 && threadIdx.x == 0) *ilist_n_next = 0;
   if (ilist) {
     int n = *ilist_n;
@@ -1612,7 +1617,8 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
   SparseArgs a = make_args(h, h->P);
   if (h->fast_rows || h->item_mode || h->list_mode) {
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
-    const bool zw = h->item_mode && a.d && h->cfg.feat_dtype != BPRX_F_FP32;      // bf16 W image: rows of untouched items
+    const bool zw = h->item_mode && a.d && h->cfg.feat_dtype != BPRX_F_FP32 && !h->pf_launching;   // bf16 W image: rows of untouched items
+    // (a prefetched pass runs while the previous step still writes / reads that image: its dense update zeroes it instead)
     const int64_t cap = 2 * B < (int64_t)a.I ? 2 * B : (int64_t)a.I;
     hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI,
                        a.fastU, (a.fastI || h->list_mode) ? 1 : 0, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
@@ -1799,7 +1805,10 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
                      lm ? h->ilist_n + (h->list_slot ^ 1) : (int32_t *)nullptr, (int)bound, h->W,
                      (lm && h->list_reset_cnt) ? h->cntI : (int32_t *)nullptr,
                      // fp8: the slot the next k_cast_Et8 reads (cleared by the last one)
-                     h->cfg.feat_dtype == BPRX_F_FP8 ? (uint32_t *)h->qs + 2 + h->qs_slot : (uint32_t *)nullptr);
+                     h->cfg.feat_dtype == BPRX_F_FP8 ? (uint32_t *)h->qs + 2 + h->qs_slot : (uint32_t *)nullptr,
+                     (uint4 *)(h->pf_zero_w ? h->Wb : nullptr),
+                     h->pf_zero_w ? (size_t)h->cfg.num_items * h->PS * sizeof(uint16_t) / 16 : (size_t)0);
+  h->pf_zero_w = false;
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
   h->absmax_valid = h->cfg.feat_dtype == BPRX_F_FP8;
   if (lm) { h->list_slot ^= 1; h->list_mode = 0; }      // the step's list is consumed

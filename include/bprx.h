@@ -155,6 +155,14 @@ BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
 BPRX_API int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
                            void *stream);
 BPRX_API int bprx_step_begin_dense(bprx_handle *h, void *stream);
+/* Optional pipelining hint (host-only call): user/pos/neg/B are the index buffers of the step AFTER the coming one --
+   already filled, or filled by work enqueued on the coming step's stream before that step.  The coming step then runs that
+   batch's index pass (row multiplicities, occurrence ranks, segment offsets: two latency-bound kernels that depend on the
+   indices only) on a side stream beside its own per-triplet kernels, and the step after it, called with exactly these
+   pointers and B, skips the pass.  The buffers must not change between the coming step and the end of the step that uses
+   them (i.e. alternate two sets of buffers).  Results are those of the unhinted sequence; a hint that is not followed is
+   discarded. */
+BPRX_API int bprx_hint_next_batch(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B);
 
 /* Item-sharded multi-GPU helpers.
    bprx_step_project: the item-projection prologue of the step (P = F.[E|Bp]) on its own, so that it can overlap the
@@ -238,6 +246,8 @@ BPRX_API int bprx_topk(bprx_handle *h, int32_t u0, int32_t u1, float *scores, co
    sink: >= 8 KiB of device scratch).  Returns the number of bytes the launch reads, or a negative BPRX_E_* code.  Timed by
    the caller on `stream`: the rate this device's HBM delivers to a streaming kernel, quoted beside the 8 TB/s spec. */
 BPRX_API int64_t bprx_probe_stream_read(const void *buf, int64_t bytes, void *sink, void *stream);
+/* ... with `nt` (streaming, no-retain) loads, the policy of the bf16 feature passes */
+BPRX_API int64_t bprx_probe_stream_read_nt(const void *buf, int64_t bytes, void *sink, void *stream);
 /* Measurement helper: n lane groups each move one row of table[num_rows][row_floats] (fp32, row_floats a multiple of 4)
    picked by idx[] -- mode 0: read; mode 1: read and write back in place (idx distinct).  The access shape of the sparse
    kernels (a table row per index): the rate quoted beside their gather/scatter roofline.  Returns the bytes moved. */

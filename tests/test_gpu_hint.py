@@ -1,0 +1,74 @@
+"""bprx_hint_next_batch: the next step's index pass (k_row_count + k_seg_alloc) is launched by the running step on a side
+stream, into a second set of index state.  The hinted sequence must give what the unhinted one gives (same kernels on the
+same inputs; what differs is the order of fp32 atomics in the user staging: 2e-5 relative), also when a hint is not
+followed (other buffers, another batch size, a list-mode step in between)."""
+import numpy as np
+import pytest
+import torch
+
+from fashionvisualexpl_recommend_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(model, U, I, k, d, D, dtype, seed=5):
+    rs = np.random.RandomState(seed)
+    t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k), Bi=(rs.standard_normal(I) * 0.01).astype(np.float32))
+    if model == "vbpr":
+        F = synth.make_features(I, D, seed=seed)
+        F = (F / np.abs(F).max()).astype(np.float32)
+        if dtype == "bf16":
+            F = orc.bf16_round(F)
+        elif dtype == "fp8":
+            F = orc.e4m3_round(F * np.float32(448.0)) / np.float32(448.0)
+        t.update(Tu=synth.glorot_uniform(rs, U, d), F=F, E=synth.glorot_uniform(rs, D, d), Bp=synth.glorot_uniform(rs, D, 1).reshape(-1))
+    return t
+
+
+def _batch(U, I, B, seed, hot=False):
+    rs = np.random.RandomState(seed)
+    u, i, j = rs.randint(U, size=B), rs.randint(I, size=B), rs.randint(I, size=B)
+    u[:5] = 7; i[8:11] = 11; j[12] = i[13]
+    if hot:
+        i[: B // 3] = 3                                   # a hot item: more than one 32-entry chunk
+    return [torch.as_tensor(a.astype(np.int32), device="cuda") for a in (u, i, j)]
+
+
+@pytest.mark.parametrize("model,dtype,opt", [("vbpr", "bf16", "sgd"), ("vbpr", "fp8", "sgd"), ("vbpr", "fp32", "sgd"),
+                                             ("vbpr", "bf16", "adam_tf23"), ("bprmf", "fp32", "sgd")])
+def test_hinted_sequence_equals_unhinted(model, dtype, opt):
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    U, I, k, d, D, B = 700, 500, 16, 12, 256, 640          # 2B >= I: segment mode
+    t = _tables(model, U, I, k, d, D, dtype)
+    kw = dict(model=model, num_users=U, num_items=I, embed_k=k, optimizer=opt, lr=0.05 if opt == "sgd" else 0.01, reg=1e-3,
+              max_batch=B, device=0)
+    if model == "vbpr":
+        kw.update(embed_d=d, feat_dim=D, feat_dtype=dtype)
+    c = lambda a: torch.as_tensor(a.copy())
+    eh = Engine(**kw).bind(**{n: c(v) for n, v in t.items()})
+    ep = Engine(**kw).bind(**{n: c(v) for n, v in t.items()})
+    st = torch.cuda.Stream()
+    # the batches of the sequence; step 4 is a small (list-mode / atomic-mode) batch, step 6 is announced but NOT followed
+    Bs = [B, B, B - 64, B, 100, B, B, B, B]
+    batches = [_batch(U, I, b, 50 + n, hot=(n == 2)) for n, b in enumerate(Bs)]
+    decoy = _batch(U, I, B, 999)
+    with torch.cuda.stream(st):
+        for n, bt in enumerate(batches):
+            if n + 1 < len(batches):
+                eh.hint_next_batch(*(decoy if n + 1 == 6 else batches[n + 1]))
+            lh = eh.step(*bt)
+            lp = ep.step(*[x.clone() for x in bt])
+            st.synchronize()
+            np.testing.assert_allclose(float(lh), float(lp), rtol=2e-5, err_msg="loss of step %d" % n)
+            if n == 3 and model == "vbpr":                 # a read between a step that prefetched and the step that uses it
+                np.testing.assert_allclose(eh.score_block(0, 32).cpu().numpy(), ep.score_block(0, 32).cpu().numpy(),
+                                           rtol=2e-3 if dtype != "fp32" else 2e-5, atol=1e-5)
+    eh.sync_check(); ep.sync_check()
+    rt, at = (2e-5, 2e-6) if dtype == "fp32" else (2e-4, 2e-6)
+    if opt != "sgd":
+        at = max(at, 2e-2 * 0.01)                          # adam: see tests/test_gpu_dist.py (near-zero summed gradients)
+    for n in t:
+        if n == "F":
+            continue
+        np.testing.assert_allclose(eh.t[n].cpu().numpy(), ep.t[n].cpu().numpy(), rtol=rt, atol=at, err_msg=n)
