@@ -532,13 +532,21 @@ __global__ __launch_bounds__(256) void k_apply_sgd(float *Gu, float *Gi, float *
   int row;
   uint32_t *flag;
   int32_t *cntp;
-  if (kind == 0) { row = clamp_idx(user[b], a.U, a.errflag, 1); flag = a.flagU + row; cntp = a.cntU + row; }
-  else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; cntp = a.cntI + row; }
+  // Users: only the first occurrence of a RUN of equal users tries the claim -- whatever the batch order, every touched user
+  // has a run head, and in the reference's user-grouped order (~20 triplets per user) that is 1 claim atomic in 20
+  // (memory-side atomics: 65 536 of them were most of this kernel on C2)
+  bool head = true;
+  if (kind == 0) {
+    const int ur = user[b], up = b > 0 ? user[b - 1] : -1;
+    head = b == 0 || up != ur;
+    row = clamp_idx(ur, a.U, a.errflag, 1); flag = a.flagU + row; cntp = a.cntU + row;
+  } else { row = clamp_idx(kind == 1 ? pos[b] : neg[b], a.I, a.errflag, 2); flag = a.flagI + row; cntp = a.cntI + row; }
   if (kind == 0 ? a.fastU : a.fastI) {                 // rows with multiplicity 1 were finished by k_triplet_grad
     const int c1 = *cntp;
     if (lane == 0 && c1) *cntp = 0;                    // reset for the next step (every job of the row may do it)
     if (c1 == 1) return;
   }
+  if (!head) return;
   unsigned claimed = 0;
   if (lane == 0) claimed = atomicExch(flag, 0u);
   claimed = __shfl(claimed, 0, G);
@@ -823,7 +831,9 @@ __global__ __launch_bounds__(256) void k_adam_apply_lazy(AdamTables T, AdamLazy 
   if (job >= (int64_t)end_kind * B) return;
   const int kind = (int)(job / B);
   const int64_t b = job - (int64_t)kind * B;
-  const int row = kind == 0 ? clamp_quiet(user[b], T.U) : clamp_quiet(kind == 1 ? pos[b] : neg[b], T.I);
+  const int raw = kind == 0 ? user[b] : (kind == 1 ? pos[b] : neg[b]);
+  if (kind == 0 && b > 0 && user[b - 1] == raw) return;    // users: run heads only (see k_apply_sgd)
+  const int row = clamp_quiet(raw, kind == 0 ? T.U : T.I);
   uint32_t *flag = kind == 0 ? flagU + row : flagI + row;
   unsigned claimed = 0;
   if (lane == 0) claimed = atomicExch(flag, 0u);
