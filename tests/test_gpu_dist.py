@@ -151,7 +151,9 @@ def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather
                                c(t["Bp"]), lr, reg, max_batch=B, user_cap=U, feat_dtype=dtype, device=0, optimizer=opt,
                                dense_reduce=dense_reduce, overlap=overlap)
         o = orc.OracleModel(**t, quant=1 if dtype == "bf16" else 0)
-        for step in range(4 if opt != "sgd" else 3):
+        nsteps = 4 if opt != "sgd" else 3
+        all_batches = []
+        for step in range(nsteps):
             batches = []
             for r in range(world):
                 br = np.random.RandomState(300 + step * world + r)
@@ -160,9 +162,14 @@ def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather
                                 br.randint(ish, size=nb).astype(np.int32)))
             if opt != "sgd" and step >= 2:                # adam: some users only in the OTHER rank's batch, some in nobody's
                 batches = [(b[0] % (10 + 7 * r) + 20 * r, b[1], b[2]) for r, b in enumerate(batches)]
-            u, i, j = batches[rank]
-            dev = lambda a: torch.as_tensor(a, device="cuda")
-            m.step(dev(u), dev(i), dev(j))
+            all_batches.append(batches)
+        dev = lambda a: torch.as_tensor(a, device="cuda")
+        mine = [tuple(dev(x) for x in bs[rank]) for bs in all_batches]
+        for step in range(nsteps):
+            batches = all_batches[step]
+            if step + 1 < nsteps:                         # the next step's index pass beside this step (bprx_hint_next_batch)
+                m.eng.hint_next_batch(*mine[step + 1])
+            m.step(*mine[step])
             o.step(np.concatenate([b[0] for b in batches]), np.concatenate([b[1] + r * ish for r, b in enumerate(batches)]),
                    np.concatenate([b[2] + r * ish for r, b in enumerate(batches)]), opt, lr, reg)
         m.eng.sync_check()
