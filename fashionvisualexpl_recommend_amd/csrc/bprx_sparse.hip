@@ -157,14 +157,24 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
     __shared__ int lw[2][4], lbase[2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     bool ai = false, aj = false, su = false, si = false, sj = false;
+    // Users: neighbouring lanes with the same user (the reference's user-grouped order: ~20 triplets per user) add ONCE,
+    // through the first lane of their run -- the memory-side atomics are what this kernel waits for (196 K of them at
+    // B = 65 536), and a run of n finds the values old, old+1, ..., old+n-1 exactly as n single adds would have.
+    const unsigned long long vm = __ballot(valid);                  // (valid lanes are a prefix of the wave: b < B)
+    const int up = __shfl_up(u, 1, 64);
+    const bool uhead = valid && (lane == 0 || up != u);
+    const unsigned long long hm = __ballot(uhead);
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);          // lanes 0 .. lane
+    const int hl = (hm & le) ? 63 - __clzll((long long)(hm & le)) : lane;                 // first lane of my run
+    const unsigned long long stops = (hm | ~vm) & ~(hl == 63 ? ~0ull : ((2ull << hl) - 1ull));
+    const int run_end = stops ? __ffsll((long long)stops) - 1 : 64;                       // first lane after my run
+    int ou = -1, oi = -1, oj = -1, hu = -1;
+    // (the item atomics first, the run heads' user atomic behind them: the wait at the end of that branch covers all three)
+    if (valid && doI) { oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1); }      // i == j: the second add returns one more
+    if (valid && doU && lane == hl) hu = atomicAdd(cntU + u, run_end - hl);
+    hu = __shfl(hu, hl, 64);
+    if (valid && doU) ou = hu + (lane - hl);
     if (valid) {
-      int ou = -1, oi = -1, oj = -1;
-      if (doU && doI) {                          // (one block: behind a branch of its own each atomic is waited for on the spot)
-        ou = atomicAdd(cntU + u, 1); oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1);
-      } else {
-        if (doU) ou = atomicAdd(cntU + u, 1);
-        if (doI) { oi = atomicAdd(cntI + i, 1); oj = atomicAdd(cntI + j, 1); }   // i == j: the second add returns one more
-      }
       ai = ilist && oi == 0; aj = ilist && oj == 0;
       su = slist && ou == 1; si = slist && oi == 1; sj = slist && oj == 1;
     }
