@@ -442,12 +442,14 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
   h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
   // the previous step may have run THIS batch's index pass already (bprx_hint_next_batch)
   bool idx_ready = false;
+  h->idx_hinted = false;
   if (h->pf_done) {
     h->pf_done = false;
     BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_pf_done, 0));
     if (h->pf_u == user && h->pf_i == pos && h->pf_j == neg && h->pf_B == B && h->item_mode && !h->proj_fresh) {
       idx_swap(h);
       idx_ready = true;
+      h->idx_hinted = true;
     } else {
       // not followed: the pass's item counts would never be consumed (k_item_seg resets what it walks)
       BPRX_HIP(h, hipMemsetAsync(h->alt.cntI, 0, (size_t)h->cfg.num_items * sizeof(int32_t), s));

@@ -66,6 +66,7 @@ struct bprx_handle {
   struct IdxAlt { int32_t *cntI, *seg_rank, *seg_ptr, *seg_cursor, *seg_lead; } alt;
   const int32_t *hint_u, *hint_i, *hint_j; int64_t hint_B;          // bprx_hint_next_batch (consumed by the next step)
   const int32_t *pf_u, *pf_i, *pf_j; int64_t pf_B; bool pf_done;    // index pass of that batch in flight / finished in `alt`
+  bool idx_hinted;                // the running step uses index state that a hint computed ahead of it (offsets are range-checked)
   bool pf_launching;              // bprx_launch_index_pass runs for the prefetched batch (no W-image zeroing there)
   bool pf_zero_w;                 // this step's k_dense_update re-zeroes the bf16 W image (the prefetched pass could not)
   hipEvent_t ev_pf_fork, ev_pf_done;

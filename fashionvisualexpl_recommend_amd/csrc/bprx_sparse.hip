@@ -37,6 +37,7 @@ struct SparseArgs {
   float lr;
   // occurrence segments (item_atomics == 0)
   const int32_t *seg_lead, *seg_nlead;   // chunk leaders (occurrence numbers) and their count
+  int seg_guard;             // this step runs on index state computed ahead of it (bprx_hint_next_batch): offsets are checked
   int seg_cap;               // entries allocated (2 * max_batch): offsets are clamped to it, so that index state that does not
                              // belong to the batch (a bprx_hint_next_batch whose buffers were changed afterwards) cannot
                              // address outside the allocation
@@ -311,8 +312,11 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   int rkI = 0, rkJ = 0, spI = 0, spJ = 0;
   if (!a.item_atomics) {
     rkI = a.seg_rank[b]; rkJ = a.seg_rank[B + b]; spI = a.seg_ptr[i]; spJ = a.seg_ptr[j];
-    const unsigned eI = (unsigned)(spI + rkI), eJ = (unsigned)(spJ + rkJ), top = (unsigned)a.seg_cap - 1u;
-    spI = (int)(eI < top ? eI : top); spJ = (int)(eJ < top ? eJ : top); rkI = 0; rkJ = 0;   // (entry slots, clamped)
+    spI += rkI; spJ += rkJ; rkI = 0; rkJ = 0;             // entry slots
+    if (a.seg_guard) {
+      const unsigned top = (unsigned)a.seg_cap - 1u;
+      spI = (int)((unsigned)spI < top ? (unsigned)spI : top); spJ = (int)((unsigned)spJ < top ? (unsigned)spJ : top);
+    }
   }
   const float *gu = a.Gu + (size_t)u * k, *gi = a.Gi + (size_t)i * k, *gj = a.Gi + (size_t)j * k;
   const float *tu = d ? a.Tu + (size_t)u * d : nullptr;
@@ -1167,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   const int n = a.cntI[item];
   const int e_first = a.seg_ptr[item] + rk;
   int ns = n - rk < SEG_CAP ? n - rk : SEG_CAP;
-  if (e_first < 0 || e_first + ns > a.seg_cap) ns = 0;   // (index state of another batch: see seg_cap)
+  if (a.seg_guard && (e_first < 0 || e_first + ns > a.seg_cap)) ns = 0;   // (index state of another batch: see seg_cap)
   const int2 *ent = a.seg_ent + e_first;
   const int k = a.k, d = a.d;
   const int c4 = lane * 4;
@@ -1320,6 +1324,7 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   static const int seg_lead_env = getenv("BPRX_SEG_LEAD") ? atoi(getenv("BPRX_SEG_LEAD")) : 1;
   a.seg_lead = h->seg_lead; a.seg_nlead = (h->seg_cursor && seg_lead_env) ? h->seg_cursor + 1 : nullptr;
   a.seg_cap = (int)(2 * h->cfg.max_batch);
+  a.seg_guard = h->idx_hinted ? 1 : 0;
   // shared-row list: both sides on the exclusive-row fast path (sgd, atomic staging, no exported gradients)
   a.use_list = (h->slist && a.fastU && a.fastI) ? 1 : 0;
   static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
