@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--pos-per-user", type=int, default=20)
     ap.add_argument("--zipf", type=float, default=0.0,
                     help="> 0: positives follow a Zipf(s) item popularity instead of the uniform one (hot items)")
+    ap.add_argument("--zipf-ids", default="shuffled", choices=["shuffled", "ranked"],
+                    help="--zipf: item id of popularity rank r = a fixed random permutation of r (default) or r itself")
     ap.add_argument("--dist-mode", default="replicated", choices=["replicated", "a2a"],
                     help="N > 1, VBPR: replicated = user tables on every rank, one all-gather per step (default); "
                          "a2a = user tables range-partitioned, rows fetched / gradients returned by all-to-all")
@@ -226,7 +228,15 @@ def main():
             wts = 1.0 / torch.arange(1, samp_items + 1, device=device, dtype=torch.float64) ** args.zipf
             cdf = torch.cumsum(wts / wts.sum(), 0)
             r = torch.rand((samp_users, npu), generator=gi, device=device, dtype=torch.float64)
-            items = torch.searchsorted(cdf, r).clamp_(max=samp_items - 1).to(torch.int32).sort(dim=1).values
+            ranks = torch.searchsorted(cdf, r).clamp_(max=samp_items - 1)
+            if args.zipf_ids == "shuffled":
+                # popularity rank -> item id through a fixed random permutation: in a real catalogue the hot items are not the
+                # ids 0, 1, 2, ... (with --zipf-ids ranked the 16 hottest items share ONE 64-byte line of every per-item
+                # counter array, and the memory-side atomics on it serialise: the adversarial layout)
+                gp = torch.Generator(device=device)
+                gp.manual_seed(777)
+                ranks = torch.randperm(samp_items, generator=gp, device=device)[ranks]
+            items = ranks.to(torch.int32).sort(dim=1).values
         else:
             items = torch.randint(samp_items, (samp_users, npu), generator=gi, device=device, dtype=torch.int32).sort(dim=1).values
         indptr = torch.arange(samp_users + 1, device=device, dtype=torch.int64) * npu
@@ -422,7 +432,7 @@ def main():
                                    % (", drawn one step ahead on a side stream" if pipe else
                                       (", drawn one step ahead in the stream and announced (bprx_hint_next_batch)" if look else ""),
                                       args.pos_per_user)
-                                   + (", Zipf(%.2f) item popularity" % args.zipf if args.zipf > 0 else ""))
+                                   + (", Zipf(%.2f) item popularity, ids %s" % (args.zipf, args.zipf_ids) if args.zipf > 0 else ""))
                        if batches is None else "pre-generated uniform (u,i,j), resident"},
             "roofline": rl, "kernels": kernels,
             "step_roofline": {"bytes_per_triplet": per_trip, "achieved": value * per_trip / 1e9 / world,

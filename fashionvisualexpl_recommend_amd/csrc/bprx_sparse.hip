@@ -1225,8 +1225,26 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   if (n > SEG_CAP) {
     // ---- hot item: this group holds one chunk.  Partial sums meet in the staging rows (dGi, dBi, fp32 W); the group that
     // finishes last (counter hand-off, fences on both sides) reads the totals back and completes the item below.
-    if (hk) { atomicAdd(a.dGi + og + 0, gr.x); atomicAdd(a.dGi + og + 1, gr.y); atomicAdd(a.dGi + og + 2, gr.z); atomicAdd(a.dGi + og + 3, gr.w); }
-    if (d && hd) { atomicAdd(a.W + ow + c4 + 0, at.x); atomicAdd(a.W + ow + c4 + 1, at.y); atomicAdd(a.W + ow + c4 + 2, at.z); atomicAdd(a.W + ow + c4 + 3, at.w); }
+    // The chunk's partial rows leave in the lane = element layout (through a per-group LDS row): an atomic wave-instruction
+    // then covers contiguous dwords -- 4 memory-side requests per row of 64 floats instead of 16 with the float4 layout
+    // (each 64-B line hit by four instructions); all chunks of a hot item queue on the same few lines.
+    __shared__ __attribute__((aligned(16))) float s_hot[256 / G][4 * G];
+    float *hrow = s_hot[threadIdx.x / G];
+    float *const gdst = a.dGi + (size_t)item * k;
+    if (hk) *reinterpret_cast<float4 *>(hrow + c4) = gr;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { const int e = x * G + lane; if (e < k) atomicAdd(gdst + e, reinterpret_cast<volatile float *>(hrow)[e]); }
+    __builtin_amdgcn_wave_barrier();
+    if (d) {
+      if (hd) *reinterpret_cast<float4 *>(hrow + c4) = at;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { const int e = x * G + lane; if (e < d) atomicAdd(a.W + ow + e, reinterpret_cast<volatile float *>(hrow)[e]); }
+      __builtin_amdgcn_wave_barrier();
+    }
     if (lane == 0) { atomicAdd(a.dBi + item, gb); if (d) atomicAdd(a.W + ow + d, wl); }
     __threadfence();
     int done = 0;
@@ -1234,13 +1252,20 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
     done = __shfl(done, 0, G);
     if (done + 1 != (n + SEG_CAP - 1) / SEG_CAP) return;             // not the last chunk of this item
     __threadfence();
-    if (hk) {                                                         // totals, read where the atomics live (L2)
-      gr.x = atomicAdd(a.dGi + og + 0, 0.f); gr.y = atomicAdd(a.dGi + og + 1, 0.f);
-      gr.z = atomicAdd(a.dGi + og + 2, 0.f); gr.w = atomicAdd(a.dGi + og + 3, 0.f);
-    }
-    if (d && hd) {
-      at.x = atomicAdd(a.W + ow + c4 + 0, 0.f); at.y = atomicAdd(a.W + ow + c4 + 1, 0.f);
-      at.z = atomicAdd(a.W + ow + c4 + 2, 0.f); at.w = atomicAdd(a.W + ow + c4 + 3, 0.f);
+    // totals, read where the atomics live (memory side), in the same layout and turned back through the LDS row
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { const int e = x * G + lane; if (e < k) reinterpret_cast<volatile float *>(hrow)[e] = atomicAdd(gdst + e, 0.f); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (hk) { const volatile float *hv = hrow + c4; gr = make_float4(hv[0], hv[1], hv[2], hv[3]); }
+    __builtin_amdgcn_wave_barrier();
+    if (d) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { const int e = x * G + lane; if (e < d) reinterpret_cast<volatile float *>(hrow)[e] = atomicAdd(a.W + ow + e, 0.f); }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (hd) { const volatile float *hv = hrow + c4; at = make_float4(hv[0], hv[1], hv[2], hv[3]); }
+      __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) { gb = atomicAdd(a.dBi + item, 0.f); if (d) wl = atomicAdd(a.W + ow + d, 0.f); }
     if (lane == 0) a.hot_done[item] = 0;
