@@ -25,7 +25,7 @@ for trial in range(int(os.environ.get("FUZZ_N", "40"))):
     if B > 100:
         i[:B // 3] = i[0]; j[B // 3: B // 2] = i[0]           # a hot item, both roles
     res = []
-    for mode in ("0", "2"):
+    for mode in (("2", "2") if os.environ.get("FUZZ_SELF") == "1" else ("0", "2")):   # FUZZ_SELF=1: run-to-run spread of one mode
         os.environ["BPRX_ITEM_MODE"] = mode
         kw = dict(embed_d=d, feat_dim=D, feat_dtype=dtype) if d else {}
         e = Engine(model=model, num_users=U, num_items=I, embed_k=k, optimizer=opt, lr=0.05 if opt == "sgd" else 0.01, reg=1e-3,
@@ -37,7 +37,8 @@ for trial in range(int(os.environ.get("FUZZ_N", "40"))):
         e.close()
     (l0, t0), (l1, t1) = res
     ok = np.allclose(l0, l1, rtol=2e-4)
-    tol = 5e-3 if (dtype == "bf16" or opt != "sgd") else 2e-5
+    # (B > 100 plants a hot item with B/3 + B/6 occurrences: the two modes sum those fp32 terms in different orders)
+    tol = 5e-3 if (dtype == "bf16" or opt != "sgd") else 2e-5 * max(1.0, B / 150.0)
     for n in t0:
         diff = np.abs(t0[n] - t1[n]).max()
         if diff > tol * max(1.0, np.abs(t0[n]).max()):
