@@ -301,7 +301,7 @@ def test_sgd_mostly_exclusive_rows_with_some_duplicates(model, item_mode, monkey
 def test_hot_items_segments_and_atomic_excess(model, opt, item_mode, monkeypatch):
     """Item-side gradients by occurrence segments (BPRX_ITEM_MODE 2 = always; 1 = per step when 2B >= I, the default)
     and by global atomics (0) give the same batch-synchronous step (bf16 and fp32 feature tables).  One item occurs 180
-    times (as positive AND as negative), another 70 times: more than the 32 entries one lane group walks, so they are
+    times (as positive AND as negative), another 70 times: more than the 64 entries one lane group walks, so they are
     cut into chunks whose partial sums meet in the staging rows and are completed by the last chunk to finish."""
     monkeypatch.setenv("BPRX_ITEM_MODE", str(item_mode))
     U, I, k, B = 400, 300, 32, 512
