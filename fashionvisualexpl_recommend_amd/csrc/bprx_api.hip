@@ -395,6 +395,12 @@ extern "C" int bprx_hint_next_batch(bprx_handle *h, const int32_t *user, const i
   return BPRX_OK;
 }
 
+// where a hinted next-batch index pass is forked: 0 (default) before k_triplet_grad, 1 (BPRX_PF_AT=1) before the backward projection
+static int prefetch_fork_point() {
+  static const int at = getenv("BPRX_PF_AT") ? atoi(getenv("BPRX_PF_AT")) : 0;
+  return at;
+}
+
 static int launch_prefetch(bprx_handle *h, hipStream_t s) {
   // the NEXT batch's index pass (bprx_hint_next_batch), from here on beside this step's per-triplet / per-item kernels --
   // latency-bound on both sides, so they overlap (beside the HBM-bound forward projection the same pass only stretched both)
@@ -491,8 +497,7 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
   h->proj_fresh = false;
   if (fork_index || catchup_aside) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
   if (!fork_index && !idx_ready && !h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
-  static const int pf_at = getenv("BPRX_PF_AT") ? atoi(getenv("BPRX_PF_AT")) : 0;   // 0: beside triplet_grad.., 1: beside proj_bwd
-  if (pf_at == 0 && (rc = launch_prefetch(h, s))) return rc;
+  if (prefetch_fork_point() == 0 && (rc = launch_prefetch(h, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   h->pending_B = B;
   h->pending_stage = 1;
@@ -510,7 +515,7 @@ extern "C" int bprx_step_begin_dense(bprx_handle *h, void *stream) {
   const float lr_t = h->pend_lr;
   int rc;
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, lr_t, s))) return rc;                  // item rows + W, no float atomics
-  if (getenv("BPRX_PF_AT") && atoi(getenv("BPRX_PF_AT")) == 1 && (rc = launch_prefetch(h, s))) return rc;
+  if (prefetch_fork_point() == 1 && (rc = launch_prefetch(h, s))) return rc;
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
   // projection -- with VBPR it runs on the side stream beside it
   if (vb && h->side && (h->side_mode & 1)) {
