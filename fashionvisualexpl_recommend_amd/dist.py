@@ -353,10 +353,17 @@ class UserShardedBPRMF:
     No dense parameter, hence no all-reduce at all.  The global step equals the single-GPU batch-synchronous step on the
     concatenation of all ranks' batches.  sgd only."""
 
-    def __init__(self, rank, world, items_total, Gu_shard, Gi_shard, Bi_shard, lr, reg, max_batch, group=None, device=None):
+    def __init__(self, rank, world, items_total, Gu_shard, Gi_shard, Bi_shard, lr, reg, max_batch, group=None, device=None,
+                 fixed_cap=True, slack=2.0):
+        """fixed_cap (default): the row exchange uses equal, fixed-capacity splits (RowExchange.plan_fixed: 2B requested rows
+        spread over `world` owners, `slack` x the even share per owner): no host synchronisation inside the step, an
+        overflowing bucket raises a device flag (x.overflowed()); False: exact data-dependent splits (one `.cpu()` of the
+        split sizes per step)."""
         from .engine import Engine, scatter_add
         self._scatter_add = scatter_add
         self.rank, self.world, self.group, self.lr = rank, world, group, lr
+        self.fixed_cap = fixed_cap
+        self.cap = int(min(2 * max_batch, -(-2 * max_batch // world) * slack + 8))
         self.x = RowExchange(rank, world, items_total, group)
         k = Gu_shard.shape[1]
         self.eng = Engine(model="bprmf", num_users=Gu_shard.shape[0], num_items=2 * max_batch, embed_k=k, optimizer="sgd",
@@ -380,6 +387,21 @@ class UserShardedBPRMF:
     def step(self, u_local, i_global, j_global, want_loss=False):
         B, k = u_local.numel(), self.k
         items = torch.cat([i_global, j_global])                                   # 2B requested rows
+        if self.fixed_cap:
+            order, slot, valid, ridx = self.x.plan_fixed(items, self.cap)
+            (rows,) = self.x.fetch_fixed([self.GiBi_shard], ridx, slot, valid)    # [2B, k+1] in owner-sorted order
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(order.numel(), device=order.device)         # back to batch order
+            rows = rows.index_select(0, inv)
+            self.stage_Gi[:2 * B].copy_(rows[:, :k])
+            self.stage_Bi[:2 * B].copy_(rows[:, k])
+            loss = self.eng.step(u_local, self.iota[:B], self.iota[B:2 * B], want_loss=want_loss)
+            dG, dB = self.eng.item_grad()
+            g = torch.cat([dG[:2 * B], dB[:2 * B].reshape(-1, 1)], dim=1).index_select(0, order)
+            (back,) = self.x.give_back_fixed([g], slot, valid, self.cap)
+            self.eng.clear_item_grad(2 * B)
+            self._scatter_add(self.GiBi_shard, ridx, back.contiguous(), -self.lr)  # (index -1 = empty slot: skipped)
+            return loss
         order, sc, rc, ridx = self.x.plan(items)
         (rows,) = self.x.fetch([self.GiBi_shard], ridx, sc, rc)                   # [2B, k+1] in owner-sorted order
         inv = torch.empty_like(order)

@@ -79,7 +79,7 @@ def test_item_sharded_vbpr_two_ranks_match_oracle(dtype):
     mp.spawn(_worker, args=(2, _free_port(), dtype), nprocs=2, join=True)
 
 
-def _worker_bprmf(rank, world, port):
+def _worker_bprmf(rank, world, port, fixed_cap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -94,7 +94,8 @@ def _worker_bprmf(rank, world, port):
                  Bi=(rs.standard_normal(I) * 0.01).astype(np.float32))
         us, it = slice(rank * ush, (rank + 1) * ush), slice(rank * ish, min(I, (rank + 1) * ish))
         c = lambda a: torch.as_tensor(a.copy())
-        m = UserShardedBPRMF(rank, world, I, c(t["Gu"][us]), c(t["Gi"][it]), c(t["Bi"][it]), lr, reg, max_batch=B, device=0)
+        m = UserShardedBPRMF(rank, world, I, c(t["Gu"][us]), c(t["Gi"][it]), c(t["Bi"][it]), lr, reg, max_batch=B, device=0,
+                             fixed_cap=fixed_cap)
         o = orc.OracleModel(**t)
         for step in range(3):
             batches = []
@@ -115,6 +116,8 @@ def _worker_bprmf(rank, world, port):
             o.step(np.concatenate([b[0] + r * ush for r, b in enumerate(batches)]), np.concatenate([b[1] for b in batches]),
                    np.concatenate([b[2] for b in batches]), "sgd", lr, reg)
         m.eng.sync_check()
+        if fixed_cap:
+            assert not m.x.overflowed()
         chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
         chk(m.eng.t["Gu"], o.Gu[us], "Gu shard")
         chk(m.Gi_shard, o.Gi[it], "Gi shard")
@@ -123,8 +126,10 @@ def _worker_bprmf(rank, world, port):
         dist.destroy_process_group()
 
 
-def test_user_sharded_bprmf_two_ranks_match_oracle():
-    mp.spawn(_worker_bprmf, args=(2, _free_port()), nprocs=2, join=True)
+@pytest.mark.parametrize("fixed_cap", [True, False])
+def test_user_sharded_bprmf_two_ranks_match_oracle(fixed_cap):
+    """fixed_cap: equal, fixed-capacity all-to-all splits (no host synchronisation inside the step); False: exact splits."""
+    mp.spawn(_worker_bprmf, args=(2, _free_port(), fixed_cap), nprocs=2, join=True)
 
 
 def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather", overlap=True):
