@@ -96,24 +96,26 @@ class UserRowExchange:
         return out
 
     def plan_fixed(self, u_global, cap):
-        """Returns (order, slot, valid, recv_idx): `order` sorts the batch by owner; sorted entry p sits in send slot slot[p]
-        (owner * cap + position inside the owner's bucket) when valid[p]; recv_idx [world*cap] are the shard-local row ids
-        the other ranks ask this rank for (-1 = empty slot)."""
+        """Returns (order, slot, valid, recv_idx): request r sits in send slot slot[r] (owner * cap + its position among the
+        requests to that owner, in batch order) when valid[r]; recv_idx [world*cap] are the shard-local row ids the other
+        ranks ask this rank for (-1 = empty slot).  `order` is the identity (kept for the callers' signature: rows come back
+        in BATCH order).  No sort and nothing that reads a size back to the host: positions are a running count per owner
+        (one-hot cumsum over the <= 8 owners), invalid requests are written to a dump slot instead of being masked out
+        (boolean-mask indexing, bincount and nonzero all synchronise)."""
         dev = u_global.device
+        n, W = u_global.numel(), self.world
         owner = torch.div(u_global, self.ush, rounding_mode="floor").to(torch.int64)
-        order = torch.argsort(owner, stable=True)
-        so = owner[order]
-        counts = torch.bincount(owner, minlength=self.world)
-        start = torch.cumsum(counts, 0) - counts
-        pos = torch.arange(u_global.numel(), device=dev) - start[so]
+        run = (owner[:, None] == torch.arange(W, device=dev)[None, :]).to(torch.int32).cumsum(0)     # [n, W]
+        pos = run.gather(1, owner[:, None]).squeeze(1).to(torch.int64) - 1
         valid = pos < cap
-        slot = so * cap + pos
-        local = (u_global[order] - so * self.ush).to(torch.int32)
-        send = torch.full((self.world * cap,), -1, dtype=torch.int32, device=dev)
-        send[slot[valid]] = local[valid]
-        flag = (counts > cap).any()
+        slot = owner * cap + pos
+        local = (u_global.to(torch.int64) - owner * self.ush).to(torch.int32)
+        send = torch.full((W * cap + 1,), -1, dtype=torch.int32, device=dev)
+        send.scatter_(0, torch.where(valid, slot, torch.full_like(slot, W * cap)), local)             # dump slot: W * cap
+        flag = (run[-1] > cap).any()
         self._overflow = flag if getattr(self, "_overflow", None) is None else (self._overflow | flag)
-        return order, slot, valid, self._a2a_equal(send)
+        order = torch.arange(n, device=dev)
+        return order, slot, valid, self._a2a_equal(send[:W * cap].contiguous())
 
     def overflowed(self):
         """True if any bucket of any plan_fixed() since the last call overflowed (synchronises)."""
@@ -137,9 +139,9 @@ class UserRowExchange:
         (rows of empty slots are zero and carry index -1: bprx_scatter_add skips them)."""
         widths = [g.shape[1] for g in grad_rows]
         packed = torch.cat(list(grad_rows), dim=1) if len(grad_rows) > 1 else grad_rows[0]
-        send = torch.zeros((self.world * cap, packed.shape[1]), dtype=packed.dtype, device=packed.device)
-        send[slot[valid]] = packed[valid]
-        return list(torch.split(self._a2a_equal(send), widths, dim=1))
+        send = torch.zeros((self.world * cap + 1, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        send.index_copy_(0, torch.where(valid, slot, torch.full_like(slot, self.world * cap)), packed)   # (dump row: W * cap)
+        return list(torch.split(self._a2a_equal(send[:self.world * cap]), widths, dim=1))
 
     def give_back(self, grad_rows, send_counts, recv_counts):
         """Send per-row gradients (batch-sorted order, concatenated column-wise: ONE collective) to the owners; returns
@@ -215,8 +217,7 @@ class ItemShardedVBPR:
         gu, tu = self.x.fetch_fixed([self.Gu_shard, self.Tu_shard], ridx, slot, valid)
         self.stage_Gu[:B].copy_(gu)
         self.stage_Tu[:B].copy_(tu)
-        i_s, j_s = i_local[order].contiguous(), j_local[order].contiguous()
-        self.eng.step_begin(self.iota[:B], i_s, j_s)
+        self.eng.step_begin(self.iota[:B], i_local, j_local)     # (rows arrive in batch order: nothing to permute)
         if self.world > 1:
             if self.x.host_staged:
                 h = self.dense.cpu()
@@ -389,15 +390,12 @@ class UserShardedBPRMF:
         items = torch.cat([i_global, j_global])                                   # 2B requested rows
         if self.fixed_cap:
             order, slot, valid, ridx = self.x.plan_fixed(items, self.cap)
-            (rows,) = self.x.fetch_fixed([self.GiBi_shard], ridx, slot, valid)    # [2B, k+1] in owner-sorted order
-            inv = torch.empty_like(order)
-            inv[order] = torch.arange(order.numel(), device=order.device)         # back to batch order
-            rows = rows.index_select(0, inv)
+            (rows,) = self.x.fetch_fixed([self.GiBi_shard], ridx, slot, valid)    # [2B, k+1] in batch order
             self.stage_Gi[:2 * B].copy_(rows[:, :k])
             self.stage_Bi[:2 * B].copy_(rows[:, k])
             loss = self.eng.step(u_local, self.iota[:B], self.iota[B:2 * B], want_loss=want_loss)
             dG, dB = self.eng.item_grad()
-            g = torch.cat([dG[:2 * B], dB[:2 * B].reshape(-1, 1)], dim=1).index_select(0, order)
+            g = torch.cat([dG[:2 * B], dB[:2 * B].reshape(-1, 1)], dim=1)
             (back,) = self.x.give_back_fixed([g], slot, valid, self.cap)
             self.eng.clear_item_grad(2 * B)
             self._scatter_add(self.GiBi_shard, ridx, back.contiguous(), -self.lr)  # (index -1 = empty slot: skipped)

@@ -324,3 +324,43 @@ def test_train_rec_cli_item_sharded_two_ranks(tmp_path):
     F += 0.5 * np.eye(12, 128, dtype=np.float32)[cl] * 3          # features that carry the cluster: VBPR can use them
     synth.write_dataset(str(tmp_path), "shd", tr, va, te, 240, features=F.astype(np.float64))
     mp.spawn(_worker_cli, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _worker_nosync(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from fashionvisualexpl_recommend_amd import synth
+        from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR, UserShardedBPRMF
+        rs = np.random.RandomState(3)
+        U, I, k, d, D, B = 300, 256, 16, 8, 128, 200
+        c = lambda a: torch.as_tensor(a.copy())
+        F = synth.make_features(I, D, seed=3)
+        F = (F / np.abs(F).max()).astype(np.float32)
+        mf = UserShardedBPRMF(0, 1, I, c(synth.glorot_uniform(rs, U, k)), c(synth.glorot_uniform(rs, I, k)),
+                              c(np.zeros(I, np.float32)), 0.05, 1e-3, max_batch=B, device=0)
+        vb = ItemShardedVBPR(0, 1, U, c(synth.glorot_uniform(rs, U, k)), c(synth.glorot_uniform(rs, U, d)),
+                             c(synth.glorot_uniform(rs, I, k)), c(np.zeros(I, np.float32)), c(F), c(synth.glorot_uniform(rs, D, d)),
+                             c(synth.glorot_uniform(rs, D, 1).reshape(-1)), 0.05, 1e-3, max_batch=B, feat_dtype="fp32", device=0)
+        dev = lambda a: torch.as_tensor(a.astype(np.int32), device="cuda")
+        bt = [(dev(rs.randint(U, size=B)), dev(rs.randint(I, size=B)), dev(rs.randint(I, size=B))) for _ in range(4)]
+        for m in (mf, vb):
+            m.step(*bt[0]); m.step(*bt[1])                     # lazy allocations, first-use paths
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("error")           # any synchronising call inside the step now raises
+            try:
+                m.step(*bt[2]); m.step(*bt[3])
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
+            assert not m.x.overflowed()
+            m.eng.sync_check()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fixed_capacity_steps_enqueue_without_host_synchronisation():
+    """The all-to-all modes with fixed-capacity splits: torch's sync-debug mode ("error") around whole steps -- no split size,
+    mask count or index is read back to the host (one rank over RCCL: the collectives are real, the routing is the same)."""
+    mp.spawn(_worker_nosync, args=(1, _free_port()), nprocs=1, join=True)
