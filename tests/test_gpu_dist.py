@@ -343,8 +343,25 @@ def _worker_nosync(rank, world, port):
         vb = ItemShardedVBPR(0, 1, U, c(synth.glorot_uniform(rs, U, k)), c(synth.glorot_uniform(rs, U, d)),
                              c(synth.glorot_uniform(rs, I, k)), c(np.zeros(I, np.float32)), c(F), c(synth.glorot_uniform(rs, D, d)),
                              c(synth.glorot_uniform(rs, D, 1).reshape(-1)), 0.05, 1e-3, max_batch=B, feat_dtype="fp32", device=0)
+        from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR
+        reps = [ReplicatedUserVBPR(0, 1, c(synth.glorot_uniform(rs, U, k)), c(synth.glorot_uniform(rs, U, d)),
+                                   c(synth.glorot_uniform(rs, I, k)), c(np.zeros(I, np.float32)), c(F), c(synth.glorot_uniform(rs, D, d)),
+                                   c(synth.glorot_uniform(rs, D, 1).reshape(-1)), 0.05, 1e-3, max_batch=B, user_cap=U, feat_dtype="fp32",
+                                   device=0, optimizer=opt, dense_reduce=dr, overlap=ov)
+                for opt, dr, ov in (("sgd", "gather", True), ("adam_tf23", "allreduce", True), ("sgd", "gather", False))]
         dev = lambda a: torch.as_tensor(a.astype(np.int32), device="cuda")
         bt = [(dev(rs.randint(U, size=B)), dev(rs.randint(I, size=B)), dev(rs.randint(I, size=B))) for _ in range(4)]
+        for m in reps:                                       # the default multi-GPU step (bench.py --gpus N)
+            m.step(*bt[0]); m.step(*bt[1])
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                m.eng.hint_next_batch(*bt[3])
+                m.step(*bt[2]); m.step(*bt[3])
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
+            m.eng.sync_check()
         for m in (mf, vb):
             m.step(*bt[0]); m.step(*bt[1])                     # lazy allocations, first-use paths
             torch.cuda.synchronize()
@@ -361,6 +378,8 @@ def _worker_nosync(rank, world, port):
 
 
 def test_fixed_capacity_steps_enqueue_without_host_synchronisation():
-    """The all-to-all modes with fixed-capacity splits: torch's sync-debug mode ("error") around whole steps -- no split size,
-    mask count or index is read back to the host (one rank over RCCL: the collectives are real, the routing is the same)."""
+    """The replicated-user step (the default of bench.py --gpus N; overlapped and single-message order, both dense forms, both
+    optimizers) and the all-to-all modes with fixed-capacity splits: torch's sync-debug mode ("error") around whole steps --
+    no split size, mask count or index is read back to the host (one rank over RCCL: the collectives are real, the routing is
+    the same)."""
     mp.spawn(_worker_nosync, args=(1, _free_port()), nprocs=1, join=True)
