@@ -1455,6 +1455,115 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
   }
 }
 
+// The same two products, parallelised for what the reference's CLI defaults produce (train_rec.py:23,33-35: batch 256, fp32
+// features, k = 128, d = 20 -- a few hundred listed rows, 21 output columns): the kernels above give a wave 21 busy lanes
+// and a 4096-step serial loop (975 us + 158 us per step at I = 10 000, D = 4096).  Same arithmetic (every product and every
+// sum in fp64), other summation order.
+//   forward: a block = FT rows x 32 columns; its 8 lane groups of 32 take every 8th 4-element piece of k (F row pieces are
+//   16-B broadcasts, E rows are coalesced over the columns); the 8 partial sums meet in LDS, fixed order.
+constexpr int F32_RT = 2, F32_NSL = 32;                    // rows per block, k slices per block (1024 threads)
+__global__ __launch_bounds__(1024) void k_proj_fwd_f32_tile(const float *__restrict__ F, const int32_t *__restrict__ rows,
+                                                            int nrows, const int32_t *__restrict__ nrows_dev, int scatter,
+                                                            int nitems, int D, const float *__restrict__ E,
+                                                            const float *__restrict__ Bp, int d, float *__restrict__ P, int PS,
+                                                            int32_t *errflag) {
+  __shared__ double red[F32_NSL][F32_RT][32];
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
+  const int t0 = blockIdx.x * F32_RT;
+  if (t0 >= nrows) return;                                  // (block-uniform)
+  const int ks = threadIdx.x >> 5, n = threadIdx.x & 31, col = blockIdx.y * 32 + n;
+  const float *f[F32_RT];
+  int item[F32_RT];
+#pragma unroll
+  for (int r = 0; r < F32_RT; ++r) {
+    const int t = t0 + r < nrows ? t0 + r : nrows - 1;      // (rows past the end: recomputed, not stored)
+    int it = rows ? rows[t] : t;
+    if ((unsigned)it >= (unsigned)nitems) { *errflag = 2; it = 0; }
+    item[r] = it;
+    f[r] = F + (size_t)it * D;
+  }
+  double acc[F32_RT];
+#pragma unroll
+  for (int r = 0; r < F32_RT; ++r) acc[r] = 0.0;
+  const bool isE = col < d, isB = col == d;
+  // a slice's k pieces: ks*4, ks*4 + 128, ...; two pieces per trip, all loads of a trip before its arithmetic (the loop is a
+  // chain of memory round trips: 16 of them at D = 4096)
+  constexpr int STEP = F32_NSL * 4;
+  for (int kb = ks * 4; kb < D; kb += 2 * STEP) {           // D % 4 == 0 (launcher)
+    const int kb2 = kb + STEP < D ? kb + STEP : kb;         // (odd number of pieces: the last one twice, weight 0)
+    const double w2 = kb + STEP < D ? 1.0 : 0.0;
+    float e[8];
+    float4 v[F32_RT][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      e[q] = isE ? E[(size_t)(kb + q) * d + col] : (isB ? Bp[kb + q] : 0.f);
+      e[4 + q] = isE ? E[(size_t)(kb2 + q) * d + col] : (isB ? Bp[kb2 + q] : 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < F32_RT; ++r) {
+      v[r][0] = *reinterpret_cast<const float4 *>(f[r] + kb);
+      v[r][1] = *reinterpret_cast<const float4 *>(f[r] + kb2);
+    }
+#pragma unroll
+    for (int r = 0; r < F32_RT; ++r) {
+      acc[r] += (double)v[r][0].x * (double)e[0];
+      acc[r] += (double)v[r][0].y * (double)e[1];
+      acc[r] += (double)v[r][0].z * (double)e[2];
+      acc[r] += (double)v[r][0].w * (double)e[3];
+      acc[r] += w2 * ((double)v[r][1].x * (double)e[4]);
+      acc[r] += w2 * ((double)v[r][1].y * (double)e[5]);
+      acc[r] += w2 * ((double)v[r][1].z * (double)e[6]);
+      acc[r] += w2 * ((double)v[r][1].w * (double)e[7]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < F32_RT; ++r) red[ks][r][n] = acc[r];
+  __syncthreads();
+  if (ks < F32_RT && (isE || isB)) {                        // lane group r sums row r
+    const int r = ks;
+    if (t0 + r < nrows) {
+      double sum = red[0][r][n];
+      for (int q = 1; q < F32_NSL; ++q) sum += red[q][r][n];
+      const size_t o = scatter ? (size_t)item[r] : (size_t)(t0 + r);
+      P[o * PS + col] = (float)sum;
+    }
+  }
+}
+
+//   backward over a row list: a block = 8 values of k x 32 columns; its 32 lane groups take every 32nd listed row (the W row
+//   is coalesced over the columns, the 8 feature values are two 16-B broadcasts); partial sums meet in LDS, fixed order.
+constexpr int F32_NRS = 32, F32_KV = 8;
+__global__ __launch_bounds__(1024) void k_proj_bwd_f32_tile(const float *__restrict__ F, int nrows, int D,
+                                                            const float *__restrict__ W, int d, int PS, float *__restrict__ dEp,
+                                                            const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev) {
+  __shared__ double red[F32_NRS][F32_KV][32];
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
+  const int rs = threadIdx.x >> 5, n = threadIdx.x & 31, col = blockIdx.y * 32 + n, k0 = blockIdx.x * F32_KV;
+  double acc[F32_KV];
+#pragma unroll
+  for (int q = 0; q < F32_KV; ++q) acc[q] = 0.0;
+  const bool on = col <= d;
+  for (int t = rs; t < nrows; t += F32_NRS) {
+    const int item = rows ? rows[t] : t;
+    const double w = on ? (double)W[(size_t)item * PS + col] : 0.0;
+    const float *fr = F + (size_t)item * D + k0;
+    const float4 v0 = *reinterpret_cast<const float4 *>(fr), v1 = *reinterpret_cast<const float4 *>(fr + 4);
+    acc[0] += (double)v0.x * w; acc[1] += (double)v0.y * w; acc[2] += (double)v0.z * w; acc[3] += (double)v0.w * w;
+    acc[4] += (double)v1.x * w; acc[5] += (double)v1.y * w; acc[6] += (double)v1.z * w; acc[7] += (double)v1.w * w;
+  }
+#pragma unroll
+  for (int q = 0; q < F32_KV; ++q) red[rs][q][n] = acc[q];
+  __syncthreads();
+  if (on && rs < F32_KV) {                                  // lane group q sums k value q
+    const int q = rs;
+    double sum = red[0][q][n];
+    for (int x = 1; x < F32_NRS; ++x) sum += red[x][q][n];
+    const int kk = k0 + q;
+    if (col < d) dEp[(size_t)kk * d + col] = (float)sum;
+    else dEp[(size_t)D * d + kk] = (float)sum;
+  }
+}
+
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
 
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
@@ -1838,9 +1947,16 @@ int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, con
 #undef CALL
     BPRX_LAUNCH_CHECK(h, "k_proj_fwd_bf16");
   } else {
-    dim3 grid((unsigned)((nrows + 3) / 4));
-    hipLaunchKernelGGL(k_proj_fwd_f32, grid, dim3(256), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
-                       h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
+    static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 1;
+    if (f32_tile && h->cfg.feat_dim % 4 == 0) {
+      dim3 grid((unsigned)((nrows + F32_RT - 1) / F32_RT), (unsigned)((h->cfg.embed_d + 1 + 31) / 32));
+      hipLaunchKernelGGL(k_proj_fwd_f32_tile, grid, dim3(F32_NSL * 32), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
+                         h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
+    } else {
+      dim3 grid((unsigned)((nrows + 3) / 4));
+      hipLaunchKernelGGL(k_proj_fwd_f32, grid, dim3(256), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
+                         h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
+    }
     BPRX_LAUNCH_CHECK(h, "k_proj_fwd_f32");
   }
   return BPRX_OK;
@@ -1880,6 +1996,12 @@ int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s) {
   } else {
     {
       BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
+      static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 1;
+      // (the tiled form walks its rows with 8 lane groups per block: for a row LIST; the whole-table sum keeps one block per k)
+      if (f32_tile && h->list_mode && D % F32_KV == 0)
+        hipLaunchKernelGGL(k_proj_bwd_f32_tile, dim3(D / F32_KV, (unsigned)((d + 1 + 31) / 32)), dim3(F32_NRS * 32), 0, s, (const float *)h->t.F,
+                           (int)bound, D, h->W, d, h->PS, h->dEp, (const int32_t *)h->ilist, (const int32_t *)h->list_cur);
+      else
       hipLaunchKernelGGL(k_proj_bwd_f32, dim3(D), dim3(256), 0, s, (const float *)h->t.F, h->list_mode ? (int)bound : I, D, h->W, d,
                          h->PS, h->dEp, h->list_mode ? (const int32_t *)h->ilist : (const int32_t *)nullptr,
                          h->list_mode ? (const int32_t *)h->list_cur : (const int32_t *)nullptr);
