@@ -13,6 +13,7 @@ ABI_VERSION = 5
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2
 FLAG_DENSE_ALLREDUCE = 4
+FLAG_ADAM_SWEEP, FLAG_ADAM_LAZY = 8, 16
 
 MODEL = {"bprmf": 0, "vbpr": 1}
 OPTIMIZER = {"sgd": 0, "adam_tf23": 1}
@@ -71,6 +72,7 @@ def lib():
         "bprx_kernel_variant_safe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "bprx_set_adam_step": (C.c_int, [vp, i64]),
         "bprx_get_adam_step": (i64, [vp]),
+        "bprx_adam_is_lazy": (C.c_int, [vp]),
         "bprx_sync_adam": (C.c_int, [vp, vp]),
         "bprx_score_pairs": (C.c_int, [vp, vp, vp, i64, vp, vp]),
         "bprx_step": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
@@ -116,7 +118,7 @@ def lib():
 
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
-           "bprx_set_adam_step", "bprx_get_adam_step", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
+           "bprx_set_adam_step", "bprx_get_adam_step", "bprx_adam_is_lazy", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts", "bprx_hint_next_batch",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",

@@ -77,7 +77,8 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->optimizer != BPRX_OPT_SGD)
     CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD supports optimizer sgd only");
   if ((cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) && cfg->optimizer != BPRX_OPT_SGD &&
-      getenv("BPRX_ADAM_LAZY") && atoi(getenv("BPRX_ADAM_LAZY")) == 0)
+      ((getenv("BPRX_ADAM_LAZY") && atoi(getenv("BPRX_ADAM_LAZY")) == 0) ||
+       (!getenv("BPRX_ADAM_LAZY") && (cfg->flags & BPRX_FLAG_ADAM_SWEEP) && !(cfg->flags & BPRX_FLAG_ADAM_LAZY))))
     CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_USER_GRAD with adam_tf23 needs the lazy form (BPRX_ADAM_LAZY != 0)");
   if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->model != BPRX_MODEL_BPRMF)
     CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD is for BPRMF (VBPR keeps its items and features local)");
@@ -197,7 +198,21 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   }
   h->SK_step = h->SK;
   // adam_tf23: lazy-exact form by default (rows are replayed when read; BPRX_ADAM_LAZY=0 = the whole-table sweeps)
-  h->adam_lazy = cfg->optimizer == BPRX_OPT_ADAM_TF23 && !(getenv("BPRX_ADAM_LAZY") && atoi(getenv("BPRX_ADAM_LAZY")) == 0);
+  // adam_tf23: lazily exact (per-row replay on touch) or by whole-table sweeps -- the same arithmetic either way.  A row's replay
+  // is a serial recurrence over the steps since its last touch: with ~20 positives per user that is 20 U / B steps of ~0.15 us
+  // each, against a sweep that moves every row's (p, m, v) once per step.  Large batches (C2: 30 steps, 5 us, against a 96-us
+  // sweep) want the replay; the reference's own defaults (batch 256: 1 562 steps = 230 us, against a 25-us sweep of its small
+  // tables) want the sweeps: measured on the CLI, 20 000 x 10 000, an epoch of 1 562 steps takes 0.76 s lazily and 0.22 s with
+  // sweeps (BPRMF 0.46 / 0.10).  BPRX_ADAM_LAZY=0 / 1 forces either; exported user gradients (multi-GPU) need the lazy form.
+  h->adam_lazy = false;
+  if (cfg->optimizer == BPRX_OPT_ADAM_TF23) {
+    const double chain_us = 20.0 * (double)cfg->num_users / (double)cfg->max_batch * 0.15;
+    const double sweep_us = ((double)cfg->num_users * (cfg->embed_k + h->cfg.embed_d) + (double)cfg->num_items * (cfg->embed_k + 1)) * 24.0 / 4e6;
+    h->adam_lazy = (cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) ? true : chain_us < sweep_us;
+    if (cfg->flags & BPRX_FLAG_ADAM_SWEEP) h->adam_lazy = false;
+    if (cfg->flags & BPRX_FLAG_ADAM_LAZY) h->adam_lazy = true;
+    if (const char *e = getenv("BPRX_ADAM_LAZY")) h->adam_lazy = atoi(e) != 0;
+  }
   if (h->adam_lazy) {
     if (dalloc_zero(&h->lastU, U) != hipSuccess || dalloc_zero(&h->lastI, I) != hipSuccess ||
         dalloc_zero(&h->lr_hist, (size_t)bprx_adam_hist()) != hipSuccess) {
@@ -344,6 +359,7 @@ extern "C" int bprx_set_adam_step(bprx_handle *h, int64_t it) {
 }
 
 extern "C" int64_t bprx_get_adam_step(const bprx_handle *h) { return h ? h->adam_t : -1; }
+extern "C" int bprx_adam_is_lazy(const bprx_handle *h) { return h ? (h->adam_lazy ? 1 : 0) : BPRX_E_INVALID; }
 
 static int check_ready(bprx_handle *h, int64_t B) {
   if (!h) return BPRX_E_INVALID;

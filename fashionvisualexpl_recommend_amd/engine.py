@@ -35,7 +35,7 @@ class Engine:
     def __init__(self, model, num_users, num_items, embed_k, embed_d=0, feat_dim=0, feat_dtype="fp32",
                  optimizer="adam_tf23", lr=1e-3, reg=0.0, max_batch=256, device=None,
                  beta1=0.9, beta2=0.999, epsilon=1e-7, export_user_grad=False, export_item_grad=False, feat_scale=448.0,
-                 dense_allreduce=False):
+                 dense_allreduce=False, adam_form=None):
         if not torch.cuda.is_available():
             raise RuntimeError("fashionvisualexpl_recommend_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _ffi.lib()
@@ -51,7 +51,8 @@ class Engine:
                           lr, reg, beta1, beta2, epsilon,
                           (_ffi.FLAG_EXPORT_USER_GRAD if export_user_grad else 0) |
                           (_ffi.FLAG_EXPORT_ITEM_GRAD if export_item_grad else 0) |
-                          (_ffi.FLAG_DENSE_ALLREDUCE if dense_allreduce else 0), self.feat_scale)
+                          (_ffi.FLAG_DENSE_ALLREDUCE if dense_allreduce else 0) |
+                          {None: 0, "sweep": _ffi.FLAG_ADAM_SWEEP, "lazy": _ffi.FLAG_ADAM_LAZY}[adam_form], self.feat_scale)
         h = C.c_void_p()
         _ffi.check(None, self.lib.bprx_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -69,6 +70,9 @@ class Engine:
     @t.setter
     def t(self, v):
         self._t = v
+
+    def adam_is_lazy(self):
+        return bool(self.lib.bprx_adam_is_lazy(self.h))
 
     def sync_adam(self):
         _ffi.check(self.h, self.lib.bprx_sync_adam(self.h, _stream()))

@@ -73,10 +73,23 @@ class BPRMF(RecommenderModel):
     def _engine_kwargs(self):
         return dict(model="bprmf", num_users=self.num_users, num_items=self.num_items, embed_k=self.embed_k)
 
+    def _adam_form(self):
+        """adam_tf23 lazily-exact or by whole-table sweeps (identical arithmetic; include/bprx.h BPRX_FLAG_ADAM_*): a row's replay
+        is a serial recurrence over the steps since its last touch -- one epoch = interactions / batch steps in the reference's
+        visiting order (~0.15 us each) -- against a sweep that moves every row's (p, m, v) once per step.  The library estimates
+        this from max_batch; here the batch size and the interaction count are known."""
+        if self.optimizer_name != "adam_tf23" or os.environ.get("BPRX_ADAM_LAZY") is not None:
+            return None
+        kw = self._engine_kwargs()
+        n_pos = sum(len(pos) for pos in self.data.training_list)
+        chain_us = 0.15 * n_pos / max(1, self.batch_size)
+        elems = kw["num_users"] * (kw["embed_k"] + kw.get("embed_d", 0)) + kw["num_items"] * (kw["embed_k"] + 1)
+        return "lazy" if chain_us < elems * 24.0 / 4e6 else "sweep"
+
     def _build(self, init):
         t, _ = self._init_tables(init)
         self.engine = Engine(optimizer=self.optimizer_name, lr=self.learning_rate, reg=self.reg,
-                             max_batch=max(self.batch_size, 4096), **self._engine_kwargs())
+                             max_batch=max(self.batch_size, 4096), adam_form=self._adam_form(), **self._engine_kwargs())
         self.engine.bind(**t)
         self._alias()
 

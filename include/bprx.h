@@ -78,7 +78,11 @@ typedef struct {
    their owner ranks (row b = the user row of triplet b); the step leaves their summed gradients in the buffers of
    bprx_user_grad() instead of applying them, and the caller routes those rows back to the owners
    (bprx_scatter_add with scale = -lr) and clears them with bprx_clear_user_grad(). */
-enum { BPRX_FLAG_EXPORT_USER_GRAD = 1, BPRX_FLAG_EXPORT_ITEM_GRAD = 2, BPRX_FLAG_DENSE_ALLREDUCE = 4 };
+enum { BPRX_FLAG_EXPORT_USER_GRAD = 1, BPRX_FLAG_EXPORT_ITEM_GRAD = 2, BPRX_FLAG_DENSE_ALLREDUCE = 4,
+       BPRX_FLAG_ADAM_SWEEP = 8, BPRX_FLAG_ADAM_LAZY = 16 };
+/* BPRX_FLAG_ADAM_SWEEP / BPRX_FLAG_ADAM_LAZY: the caller's choice of adam_tf23's form (whole-table sweeps / lazily-exact replay:
+   the same arithmetic) instead of bprx_create's estimate from num_users and max_batch -- a caller that knows the real batch size
+   and the number of training interactions knows the replay depth (interactions / batch) exactly.  See bprx_adam_is_lazy. */
 /* BPRX_FLAG_DENSE_ALLREDUCE (with BPRX_FLAG_EXPORT_USER_GRAD, replicated-user step): the per-rank message carries NO dense
    part; the caller all-reduces (sum, RCCL) the buffer of bprx_dense_grad() between bprx_pack_user_msg and bprx_step_end --
    the "RCCL all-reduce on E / beta'" form of SURVEY 8(e).  Without it dE|dBp rides in the all-gathered message and is summed
@@ -128,6 +132,9 @@ BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations);         /* 
    optimizer.iterations steps.  No-op for sgd, or when nothing is pending.  (BPRX_ADAM_LAZY=0: the sweeps, for A/B.) */
 BPRX_API int bprx_sync_adam(bprx_handle *h, void *stream);
 BPRX_API int64_t bprx_get_adam_step(const bprx_handle *h);
+/* 1: adam_tf23 runs lazily-exact on this handle (per-row replay, bprx_sync_adam meaningful), 0: by whole-table sweeps.  Chosen at
+   bprx_create from the table sizes and max_batch (BPRX_ADAM_LAZY=0 / 1 forces it); the arithmetic is the same. */
+BPRX_API int bprx_adam_is_lazy(const bprx_handle *h);
 
 /* Model.call((user,item)) -> xui        BPRMF.py:55-76 / VBPR.py:59-86.   x: fp32 [B] */
 BPRX_API int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32_t *item, int64_t B, float *x, void *stream);

@@ -11,6 +11,10 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # adam_tf23: the library picks lazily-exact replay or whole-table sweeps from the table sizes and the batch size (the tests'
+    # toy shapes would mostly get sweeps).  The suite exercises the lazy form unless told otherwise (scripts/env_matrix.sh runs
+    # it again with BPRX_ADAM_LAZY=0); tests/test_gpu_adam_lazy.py::test_adam_policy... removes the variable to test the choice.
+    os.environ.setdefault("BPRX_ADAM_LAZY", "1")
 
 
 @pytest.fixture(scope="session")

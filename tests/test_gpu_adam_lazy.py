@@ -117,3 +117,35 @@ def test_snapshot_and_restore_with_pending_rows(tmp_path):
         b.step(_dev(u), _dev(i), _dev(j), want_loss=False)
     for n in want:
         np.testing.assert_allclose(b.t[n].cpu().numpy(), want[n], rtol=1e-5, atol=1e-7, err_msg=n)
+
+
+def test_adam_policy_picks_sweeps_for_small_batches_and_lazy_for_large_ones(monkeypatch):
+    """bprx_create chooses the form from 20 U / B replayed steps against the bytes of a sweep: the reference's own defaults
+    (batch 256 on small tables) get sweeps, bench-sized batches the lazy replay; either way the step is the same step
+    (bit-identical tables on a duplicate-free run)."""
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    monkeypatch.delenv("BPRX_ADAM_LAZY", raising=False)
+    mk = lambda U, I, k, B, **kw: Engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="adam_tf23", lr=0.01, reg=1e-3,
+                                         max_batch=B, **kw)
+    e = mk(20000, 10000, 128, 256)
+    assert not e.adam_is_lazy()                                     # train_rec.py defaults on a small catalogue
+    e.close()
+    e = mk(100000, 50000, 64, 65536)
+    assert e.adam_is_lazy()                                         # BASELINE.json configs[1] shape
+    e.close()
+    U, I, k, B = 3000, 4000, 32, 200
+    t = _tables(U, I, k, 0, 0, seed=4)
+    batches = _unique_batches(U, I, B, 10, seed=2)
+    res = []
+    for force in (None, "1"):
+        if force:
+            monkeypatch.setenv("BPRX_ADAM_LAZY", force)
+        e = mk(U, I, k, B).bind(**t)
+        if force is None:
+            assert not e.adam_is_lazy()
+        for u, i, j in batches:
+            e.step(_dev(u), _dev(i), _dev(j))
+        res.append({n: e.t[n].cpu().numpy().copy() for n in ("Gu", "Gi", "Bi", "m_Gu", "v_Gi")})
+        e.close()
+    for n in res[0]:
+        assert np.array_equal(res[0][n].view(np.uint32), res[1][n].view(np.uint32)), n
