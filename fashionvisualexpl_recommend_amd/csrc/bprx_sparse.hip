@@ -706,6 +706,27 @@ __global__ __launch_bounds__(256) void k_adam_sparse(float *__restrict__ p, floa
   }
 }
 
+// The four sparse-variable sweeps of a step and the clearing of the two claim-mark arrays in ONE launch (six launches of a
+// few microseconds each before: a third of a batch-256 step on the reference CLI's default shapes).  Same element function.
+struct AdamSweepSeg { float *p, *m, *v, *g; size_t n; };
+struct AdamSweepAll { AdamSweepSeg seg[4]; uint32_t *flag[2]; size_t nflag[2]; };
+__global__ __launch_bounds__(256) void k_adam_sparse_all(AdamSweepAll a, float b1, float b2, float lr_t, float eps) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const AdamSweepSeg sg = a.seg[q];
+    for (size_t e = first; e < sg.n; e += stride) {
+      float pp = sg.p[e], mm = sg.m[e], vv = sg.v[e];
+      adam_elem(pp, mm, vv, sg.g[e], b1, b2, lr_t, eps);
+      sg.p[e] = pp; sg.m[e] = mm; sg.v[e] = vv;
+      sg.g[e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    for (size_t e = first; e < a.nflag[q]; e += stride) a.flag[q][e] = 0u;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // LAZY-EXACT adam_tf23.  The sweep above moves 6*(U+I)*(k+d)*4 bytes per step whatever the batch.  A row that
 // receives no gradient in a step still changes (m, v decay; var moves by lr_s*m/(sqrt(v)+eps)), but by a recurrence that
@@ -1857,18 +1878,19 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     BPRX_LAUNCH_CHECK(h, "k_adam_apply_lazy");
     return BPRX_OK;
   }
-  auto sweep = [&](float *p, float *m, float *v, float *g, size_t n) {
-    unsigned blocks = (unsigned)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_adam_sparse, dim3(blocks), dim3(256), 0, s, p, m, v, g, n, b1, b2, lr_t, eps);
-  };
-  sweep(h->t.Bi, h->t.m_Bi, h->t.v_Bi, h->dBi, I);              // params order of BPRMF.py:117-121 / VBPR.py:132-139
-  sweep(h->t.Gu, h->t.m_Gu, h->t.v_Gu, h->dGu, U * k);
-  sweep(h->t.Gi, h->t.m_Gi, h->t.v_Gi, h->dGi, I * k);
-  if (d) sweep(h->t.Tu, h->t.m_Tu, h->t.v_Tu, h->dTu, U * d);
-  // the sgd claim marks are unused by adam: clear them so that a later optimizer switch starts clean
-  hipLaunchKernelGGL(k_clear_flags, dim3(256), dim3(256), 0, s, h->flagU, U);
-  hipLaunchKernelGGL(k_clear_flags, dim3(256), dim3(256), 0, s, h->flagI, I);
+  // params order of BPRMF.py:117-121 / VBPR.py:132-139; the sgd claim marks are unused by adam: cleared so that a later
+  // optimizer switch starts clean
+  AdamSweepAll sw;
+  sw.seg[0] = {h->t.Bi, h->t.m_Bi, h->t.v_Bi, h->dBi, I};
+  sw.seg[1] = {h->t.Gu, h->t.m_Gu, h->t.v_Gu, h->dGu, U * k};
+  sw.seg[2] = {h->t.Gi, h->t.m_Gi, h->t.v_Gi, h->dGi, I * k};
+  sw.seg[3] = {h->t.Tu, h->t.m_Tu, h->t.v_Tu, h->dTu, d ? U * d : (size_t)0};
+  sw.flag[0] = h->flagU; sw.nflag[0] = U; sw.flag[1] = h->flagI; sw.nflag[1] = I;
+  const size_t most = U * (k > d ? k : d) > I * k ? U * (k > d ? k : d) : I * k;
+  unsigned blocks = (unsigned)((most + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_adam_sparse_all, dim3(blocks), dim3(256), 0, s, sw, b1, b2, lr_t, eps);
   BPRX_LAUNCH_CHECK(h, "k_adam_sparse");
   return BPRX_OK;
 }
