@@ -1486,35 +1486,37 @@ __global__ __launch_bounds__(1024) void k_proj_fwd_f32_tile(const float *__restr
 #pragma unroll
   for (int r = 0; r < F32_RT; ++r) acc[r] = 0.0;
   const bool isE = col < d, isB = col == d;
-  // a slice's k pieces: ks*4, ks*4 + 128, ...; two pieces per trip, all loads of a trip before its arithmetic (the loop is a
-  // chain of memory round trips: 16 of them at D = 4096)
-  constexpr int STEP = F32_NSL * 4;
-  for (int kb = ks * 4; kb < D; kb += 2 * STEP) {           // D % 4 == 0 (launcher)
-    const int kb2 = kb + STEP < D ? kb + STEP : kb;         // (odd number of pieces: the last one twice, weight 0)
-    const double w2 = kb + STEP < D ? 1.0 : 0.0;
-    float e[8];
-    float4 v[F32_RT][2];
+  // a slice's k pieces: ks*4, ks*4 + 128, ...; PT pieces per trip, all loads of a trip before its arithmetic (the loop is a
+  // chain of memory round trips: 8 of them at D = 4096)
+  constexpr int STEP = F32_NSL * 4, PT = 4;
+  for (int kb = ks * 4; kb < D; kb += PT * STEP) {          // D % 4 == 0 (launcher)
+    int kq[PT];
+    double wq[PT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      e[q] = isE ? E[(size_t)(kb + q) * d + col] : (isB ? Bp[kb + q] : 0.f);
-      e[4 + q] = isE ? E[(size_t)(kb2 + q) * d + col] : (isB ? Bp[kb2 + q] : 0.f);
+    for (int x = 0; x < PT; ++x) {                          // (pieces past the end: the first one again, weight 0)
+      const bool in = kb + x * STEP < D;
+      kq[x] = in ? kb + x * STEP : kb;
+      wq[x] = in ? 1.0 : 0.0;
     }
+    float e[PT][4];
+    float4 v[F32_RT][PT];
 #pragma unroll
-    for (int r = 0; r < F32_RT; ++r) {
-      v[r][0] = *reinterpret_cast<const float4 *>(f[r] + kb);
-      v[r][1] = *reinterpret_cast<const float4 *>(f[r] + kb2);
-    }
+    for (int x = 0; x < PT; ++x)
 #pragma unroll
-    for (int r = 0; r < F32_RT; ++r) {
-      acc[r] += (double)v[r][0].x * (double)e[0];
-      acc[r] += (double)v[r][0].y * (double)e[1];
-      acc[r] += (double)v[r][0].z * (double)e[2];
-      acc[r] += (double)v[r][0].w * (double)e[3];
-      acc[r] += w2 * ((double)v[r][1].x * (double)e[4]);
-      acc[r] += w2 * ((double)v[r][1].y * (double)e[5]);
-      acc[r] += w2 * ((double)v[r][1].z * (double)e[6]);
-      acc[r] += w2 * ((double)v[r][1].w * (double)e[7]);
-    }
+      for (int q = 0; q < 4; ++q) e[x][q] = isE ? E[(size_t)(kq[x] + q) * d + col] : (isB ? Bp[kq[x] + q] : 0.f);
+#pragma unroll
+    for (int r = 0; r < F32_RT; ++r)
+#pragma unroll
+      for (int x = 0; x < PT; ++x) v[r][x] = *reinterpret_cast<const float4 *>(f[r] + kq[x]);
+#pragma unroll
+    for (int r = 0; r < F32_RT; ++r)
+#pragma unroll
+      for (int x = 0; x < PT; ++x) {
+        acc[r] += wq[x] * ((double)v[r][x].x * (double)e[x][0]);
+        acc[r] += wq[x] * ((double)v[r][x].y * (double)e[x][1]);
+        acc[r] += wq[x] * ((double)v[r][x].z * (double)e[x][2]);
+        acc[r] += wq[x] * ((double)v[r][x].w * (double)e[x][3]);
+      }
   }
 #pragma unroll
   for (int r = 0; r < F32_RT; ++r) red[ks][r][n] = acc[r];
@@ -1543,13 +1545,29 @@ __global__ __launch_bounds__(1024) void k_proj_bwd_f32_tile(const float *__restr
 #pragma unroll
   for (int q = 0; q < F32_KV; ++q) acc[q] = 0.0;
   const bool on = col <= d;
-  for (int t = rs; t < nrows; t += F32_NRS) {
-    const int item = rows ? rows[t] : t;
-    const double w = on ? (double)W[(size_t)item * PS + col] : 0.0;
-    const float *fr = F + (size_t)item * D + k0;
-    const float4 v0 = *reinterpret_cast<const float4 *>(fr), v1 = *reinterpret_cast<const float4 *>(fr + 4);
-    acc[0] += (double)v0.x * w; acc[1] += (double)v0.y * w; acc[2] += (double)v0.z * w; acc[3] += (double)v0.w * w;
-    acc[4] += (double)v1.x * w; acc[5] += (double)v1.y * w; acc[6] += (double)v1.z * w; acc[7] += (double)v1.w * w;
+  // four listed rows per trip, all loads of a trip before its arithmetic (rows past the end: the last one again, weight 0)
+  constexpr int RPT = 4;
+  for (int t = rs; t < nrows; t += RPT * F32_NRS) {
+    int item[RPT];
+    double w[RPT];
+    float4 v[RPT][2];
+#pragma unroll
+    for (int x = 0; x < RPT; ++x) {
+      const int tx = t + x * F32_NRS;
+      item[x] = rows ? rows[tx < nrows ? tx : t] : (tx < nrows ? tx : t);
+    }
+#pragma unroll
+    for (int x = 0; x < RPT; ++x) {
+      const float wv = on ? W[(size_t)item[x] * PS + col] : 0.f;
+      w[x] = t + x * F32_NRS < nrows ? (double)wv : 0.0;
+      const float *fr = F + (size_t)item[x] * D + k0;
+      v[x][0] = *reinterpret_cast<const float4 *>(fr); v[x][1] = *reinterpret_cast<const float4 *>(fr + 4);
+    }
+#pragma unroll
+    for (int x = 0; x < RPT; ++x) {
+      acc[0] += (double)v[x][0].x * w[x]; acc[1] += (double)v[x][0].y * w[x]; acc[2] += (double)v[x][0].z * w[x]; acc[3] += (double)v[x][0].w * w[x];
+      acc[4] += (double)v[x][1].x * w[x]; acc[5] += (double)v[x][1].y * w[x]; acc[6] += (double)v[x][1].z * w[x]; acc[7] += (double)v[x][1].w * w[x];
+    }
   }
 #pragma unroll
   for (int q = 0; q < F32_KV; ++q) red[rs][q][n] = acc[q];
