@@ -154,11 +154,16 @@ class Engine:
                                                          _ptr(x[s:s + n]), _stream()))
         return x
 
-    def step(self, user, pos, neg, want_loss=True):
-        """One train step on device int32 index tensors.  Returns the device loss scalar (no host sync)."""
-        _ffi.check(self.h, self.lib.bprx_step(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(),
-                                              _ptr(self._loss) if want_loss else None, _stream()))
-        return self._loss
+    def step(self, user, pos, neg, want_loss=True, loss_out=None, loss_index=0):
+        """One train step on device int32 index tensors.  Returns the device loss scalar (no host sync).
+        loss_out / loss_index: write the step's loss to element `loss_index` of this fp32 device tensor instead (a training
+        loop that reads its losses once per epoch never waits for a step)."""
+        if loss_out is not None:
+            lp = C.c_void_p(loss_out.data_ptr() + 4 * int(loss_index))
+        else:
+            lp = _ptr(self._loss) if want_loss else None
+        _ffi.check(self.h, self.lib.bprx_step(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), lp, _stream()))
+        return self._loss if loss_out is None else loss_out
 
     def step_begin(self, user, pos, neg):
         _ffi.check(self.h, self.lib.bprx_step_begin(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), _stream()))

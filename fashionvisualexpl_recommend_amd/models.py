@@ -168,10 +168,15 @@ class BPRMF(RecommenderModel):
             print('Restored epoch {0} from {1}'.format(self.restore_epochs, path))
         start_ep = time()
         print('Start training...')
+        # (the reference reads loss.numpy() after every step, BPRMF.py:125 -- a host synchronisation per step; here the
+        #  step losses land in a device buffer and are read once per epoch, so the host runs ahead of the device)
+        loss_buf = torch.zeros(max(1, steps_per_epoch), dtype=torch.float32, device=self.engine.device)
         for batch in next_batch:
             steps += 1
-            loss += self.train_step(batch)
+            user, pos, neg = (as_index(b, self.engine.device) for b in batch)
+            self.engine.step(user, pos, neg, loss_out=loss_buf, loss_index=steps - 1)
             if steps == steps_per_epoch:                                        # epoch is over
+                loss = float(loss_buf[:steps].double().sum().item())
                 epoch_text = 'Epoch {0}/{1} \tLoss: {2:.3f}'.format(it, self.params.epochs, loss / steps)
                 epoch_print = self.evaluator.eval(it, results, epoch_text, start_ep)
                 for metric in max_metrics.keys():
