@@ -199,14 +199,16 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   h->SK_step = h->SK;
   // adam_tf23: lazy-exact form by default (rows are replayed when read; BPRX_ADAM_LAZY=0 = the whole-table sweeps)
   // adam_tf23: lazily exact (per-row replay on touch) or by whole-table sweeps -- the same arithmetic either way.  A row's replay
-  // is a serial recurrence over the steps since its last touch: with ~20 positives per user that is 20 U / B steps of ~0.15 us
-  // each, against a sweep that moves every row's (p, m, v) once per step.  Large batches (C2: 30 steps, 5 us, against a 96-us
-  // sweep) want the replay; the reference's own defaults (batch 256: 1 562 steps = 230 us, against a 25-us sweep of its small
+  // is a serial recurrence over the steps since its last touch: with ~20 positives per user that is 20 U / B steps of ~0.45 us
+  // each, against a sweep that moves every row's (p, m, v) once per step.  Large batches (C2: 30 steps, 14 us, against a 96-us
+  // sweep) want the replay; the reference's own defaults (batch 256: 1 562 steps = 700 us, against a 25-us sweep of its small
   // tables) want the sweeps: measured on the CLI, 20 000 x 10 000, an epoch of 1 562 steps takes 0.76 s lazily and 0.22 s with
   // sweeps (BPRMF 0.46 / 0.10).  BPRX_ADAM_LAZY=0 / 1 forces either; exported user gradients (multi-GPU) need the lazy form.
   h->adam_lazy = false;
   if (cfg->optimizer == BPRX_OPT_ADAM_TF23) {
-    const double chain_us = 20.0 * (double)cfg->num_users / (double)cfg->max_batch * 0.15;
+    // (0.45 us per replayed step: k_adam_catchup on C2's tables takes 86 / 235 / 702 us at replay depths 122 / 488 / 1953 =
+    //  batches of 16 384 / 4 096 / 1 024, where the sweeps take 81-88 us: measured crossover between 16 384 and 4 096)
+    const double chain_us = 20.0 * (double)cfg->num_users / (double)cfg->max_batch * 0.45;
     const double sweep_us = ((double)cfg->num_users * (cfg->embed_k + h->cfg.embed_d) + (double)cfg->num_items * (cfg->embed_k + 1)) * 24.0 / 4e6;
     h->adam_lazy = (cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) ? true : chain_us < sweep_us;
     if (cfg->flags & BPRX_FLAG_ADAM_SWEEP) h->adam_lazy = false;

@@ -76,13 +76,13 @@ class BPRMF(RecommenderModel):
     def _adam_form(self):
         """adam_tf23 lazily-exact or by whole-table sweeps (identical arithmetic; include/bprx.h BPRX_FLAG_ADAM_*): a row's replay
         is a serial recurrence over the steps since its last touch -- one epoch = interactions / batch steps in the reference's
-        visiting order (~0.15 us each) -- against a sweep that moves every row's (p, m, v) once per step.  The library estimates
+        visiting order (~0.45 us each, measured: bprx_api.hip) -- against a sweep that moves every row's (p, m, v) once per step.  The library estimates
         this from max_batch; here the batch size and the interaction count are known."""
         if self.optimizer_name != "adam_tf23" or os.environ.get("BPRX_ADAM_LAZY") is not None:
             return None
         kw = self._engine_kwargs()
         n_pos = sum(len(pos) for pos in self.data.training_list)
-        chain_us = 0.15 * n_pos / max(1, self.batch_size)
+        chain_us = 0.45 * n_pos / max(1, self.batch_size)
         elems = kw["num_users"] * (kw["embed_k"] + kw.get("embed_d", 0)) + kw["num_items"] * (kw["embed_k"] + 1)
         return "lazy" if chain_us < elems * 24.0 / 4e6 else "sweep"
 
