@@ -1582,6 +1582,115 @@ __global__ __launch_bounds__(1024) void k_proj_bwd_f32_tile(const float *__restr
   }
 }
 
+// The same two products on the fp64 matrix instruction (v_mfma_f64_16x16x4_f64: products and sums in fp64, as above; what the
+// vector-ALU forms spend on 8-cycle v_fma_f64 and on converting both operands of every product goes to the matrix pipe and to
+// two conversions per four products).  Operand maps (cdna_hip_programming.md, fragment layout): lane l holds A[row l&15][k = l>>4]
+// and B[k = l>>4][col l&15]; result register r of lane l is C[row (l>>4) + 4r][col l&15].  The instruction's four k slots are
+// filled with the actual k = kb + 4*(l>>4) + s in step s (any assignment is fine as long as A and B use the same one), so a
+// lane's A values of four steps are ONE 16-byte load.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+//   forward: block = 16 rows x 16 columns, its 16 waves take every 16th 16-element piece of k; partial tiles meet in LDS.
+__global__ __launch_bounds__(1024) void k_proj_fwd_f32_mfma(const float *__restrict__ F, const int32_t *__restrict__ rows,
+                                                            int nrows, const int32_t *__restrict__ nrows_dev, int scatter,
+                                                            int nitems, int D, const float *__restrict__ E,
+                                                            const float *__restrict__ Bp, int d, float *__restrict__ P, int PS,
+                                                            int32_t *errflag) {
+  __shared__ double red[16][4][64];
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
+  const int t0 = blockIdx.x * 16;
+  if (t0 >= nrows) return;                                  // (block-uniform)
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int t = t0 + i < nrows ? t0 + i : nrows - 1;        // (rows past the end: recomputed, not stored)
+  int item = rows ? rows[t] : t;
+  if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
+  const float *fa = F + (size_t)item * D + 4 * kq;
+  const int col = blockIdx.y * 16 + i;
+  const bool isE = col < d, isB = col == d;
+  f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int nchunk = D >> 4;                                // D % 16 == 0 (launcher)
+  constexpr int PT = 4;                                     // pieces per trip: all loads of a trip before its arithmetic
+  for (int c = w; c < nchunk; c += 16 * PT) {
+    int kbx[PT];
+    double wx[PT];
+    float4 ax[PT];
+    float bx[PT][4];
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {                          // (pieces past the end: the first one again, weight 0)
+      const bool in = c + 16 * x < nchunk;
+      kbx[x] = (in ? c + 16 * x : c) << 4;
+      wx[x] = in ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {
+      ax[x] = *reinterpret_cast<const float4 *>(fa + kbx[x]);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int kk = kbx[x] + 4 * kq + s4;
+        bx[x][s4] = isE ? E[(size_t)kk * d + col] : (isB ? Bp[kk] : 0.f);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ax[x].x * wx[x], (double)bx[x][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ax[x].y * wx[x], (double)bx[x][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ax[x].z * wx[x], (double)bx[x][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ax[x].w * wx[x], (double)bx[x][3], acc, 0, 0, 0);
+    }
+  }
+  red[w][0][lane] = acc.x; red[w][1][lane] = acc.y; red[w][2][lane] = acc.z; red[w][3][lane] = acc.w;
+  __syncthreads();
+  if (w < 4) {                                              // wave r sums result register r of the 16 partial tiles
+    double sum = red[0][w][lane];
+    for (int x = 1; x < 16; ++x) sum += red[x][w][lane];
+    const int row = (lane >> 4) + 4 * w, oc = blockIdx.y * 16 + (lane & 15);
+    if (t0 + row < nrows && oc <= d) {
+      const int trow = t0 + row;
+      int it = rows ? rows[trow] : trow;
+      if ((unsigned)it >= (unsigned)nitems) it = 0;
+      const size_t o = scatter ? (size_t)it : (size_t)trow;
+      P[o * PS + oc] = (float)sum;
+    }
+  }
+}
+
+//   backward over a row list: block = 16 values of k x 16 columns, its 4 waves take every 4th 16-row piece of the list.
+__global__ __launch_bounds__(256) void k_proj_bwd_f32_mfma(const float *__restrict__ F, int nrows, int D,
+                                                           const float *__restrict__ W, int d, int PS, float *__restrict__ dEp,
+                                                           const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev) {
+  __shared__ double red[4][4][64];
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int k0 = blockIdx.x * 16, col = blockIdx.y * 16 + i;
+  const bool on = col <= d;
+  f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int nchunk = (nrows + 15) >> 4;
+  for (int c = w; c < nchunk; c += 4) {
+    const int tb = (c << 4) + 4 * kq;
+    int it[4];
+    float wv[4], fv[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int t = tb + s4;
+      it[s4] = rows ? rows[t < nrows ? t : nrows - 1] : (t < nrows ? t : nrows - 1);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      fv[s4] = F[(size_t)it[s4] * D + k0 + i];
+      wv[s4] = (on && tb + s4 < nrows) ? W[(size_t)it[s4] * PS + col] : 0.f;     // (rows past the end: weight 0)
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fv[s4], (double)wv[s4], acc, 0, 0, 0);
+  }
+  red[w][0][lane] = acc.x; red[w][1][lane] = acc.y; red[w][2][lane] = acc.z; red[w][3][lane] = acc.w;
+  __syncthreads();
+  {                                                         // wave r sums result register r of the 4 partial tiles
+    const double sum = (red[0][w][lane] + red[1][w][lane]) + (red[2][w][lane] + red[3][w][lane]);
+    const int kk = k0 + (lane >> 4) + 4 * w, oc = blockIdx.y * 16 + (lane & 15);
+    if (oc < d) dEp[(size_t)kk * d + oc] = (float)sum;
+    else if (oc == d) dEp[(size_t)D * d + kk] = (float)sum;
+  }
+}
+
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
 
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
@@ -1965,8 +2074,12 @@ int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, con
 #undef CALL
     BPRX_LAUNCH_CHECK(h, "k_proj_fwd_bf16");
   } else {
-    static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 1;
-    if (f32_tile && h->cfg.feat_dim % 4 == 0) {
+    static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 2;
+    if (f32_tile >= 2 && h->cfg.feat_dim % 16 == 0) {     // (2, the default: fp64 matrix instruction; 1: vector-ALU tiles; 0: first form)
+      dim3 grid((unsigned)((nrows + 15) / 16), (unsigned)((h->cfg.embed_d + 1 + 15) / 16));
+      hipLaunchKernelGGL(k_proj_fwd_f32_mfma, grid, dim3(1024), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
+                         h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
+    } else if (f32_tile && h->cfg.feat_dim % 4 == 0) {
       dim3 grid((unsigned)((nrows + F32_RT - 1) / F32_RT), (unsigned)((h->cfg.embed_d + 1 + 31) / 32));
       hipLaunchKernelGGL(k_proj_fwd_f32_tile, grid, dim3(F32_NSL * 32), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
                          h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
@@ -2014,9 +2127,14 @@ int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s) {
   } else {
     {
       BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
-      static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 1;
-      // (the tiled form walks its rows with 8 lane groups per block: for a row LIST; the whole-table sum keeps one block per k)
-      if (f32_tile && h->list_mode && D % F32_KV == 0)
+      static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 2;
+      // (the tiled forms split the listed rows over the lane groups / waves of a block: for a row LIST; the whole-table sum
+      //  keeps one block per k)
+      // (the fp64-matrix form of the backward sum is no faster than the vector-ALU tiles here -- 19 vs 17 us: BPRX_F32_TILE=3)
+      if (f32_tile >= 3 && h->list_mode && D % 16 == 0)
+        hipLaunchKernelGGL(k_proj_bwd_f32_mfma, dim3(D / 16, (unsigned)((d + 1 + 15) / 16)), dim3(256), 0, s, (const float *)h->t.F,
+                           (int)bound, D, h->W, d, h->PS, h->dEp, (const int32_t *)h->ilist, (const int32_t *)h->list_cur);
+      else if (f32_tile && h->list_mode && D % F32_KV == 0)
         hipLaunchKernelGGL(k_proj_bwd_f32_tile, dim3(D / F32_KV, (unsigned)((d + 1 + 31) / 32)), dim3(F32_NRS * 32), 0, s, (const float *)h->t.F,
                            (int)bound, D, h->W, d, h->PS, h->dEp, (const int32_t *)h->ilist, (const int32_t *)h->list_cur);
       else
