@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps between barrier + synchronize) is run this many times; "
                          "value / ms_per_step are the MEDIAN repeat, every repeat is listed in repeats_ms")
+    ap.add_argument("--min-timed-seconds", type=float, default=2.0,
+                    help="repeat the timed region until the timed GPU work adds up to at least this (see --repeats)")
+    ap.add_argument("--max-repeats", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
@@ -318,11 +321,27 @@ def main():
     with torch.cuda.stream(run_stream):
         for s in range(W):
             one_step(s)
-        for rep in range(max(1, args.repeats)):
+        # Every timed region is EXACTLY K steps between barrier + synchronize.  A region of the driver's K = 20 is ~5 ms of
+        # GPU work, invisible to an outside utilisation sampler, so the region is repeated until the timed GPU work adds up to
+        # --min-timed-seconds (default 2 s): an untimed pilot region sizes the repeat count (the same on every rank: MAX over
+        # ranks), the median region is the one reported, every region is listed in repeats_ms.
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(K):
+            one_step(W + s)
+        barrier()
+        pilot = time.perf_counter() - t0
+        if world > 1:
+            pt = torch.tensor([pilot], device="cpu" if rehearse else device, dtype=torch.float64)
+            dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+            pilot = float(pt.item())
+        n_rep = max(1, args.repeats, int(np.ceil(args.min_timed_seconds / max(pilot, 1e-6))))
+        n_rep = min(n_rep, args.max_repeats)
+        for rep in range(n_rep):
             barrier()
             t0 = time.perf_counter()
             for s in range(K):                                # EXACTLY K steps between barrier + synchronize
-                one_step(W + rep * K + s)
+                one_step(W + (rep + 1) * K + s)
             barrier()
             repeats.append(time.perf_counter() - t0)
     torch.cuda.current_stream().wait_stream(run_stream)
@@ -412,7 +431,8 @@ def main():
                 rl["mfma_util"] = mu
         out = {
             "metric": "BPR triplets/sec", "value": value, "unit": "triplets/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": elapsed / K * 1e3, "repeats_ms": [r / K * 1e3 for r in repeats],
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "repeats": len(repeats), "timed_region_s": float(sum(repeats)),
+            "repeats_ms": [round(r / K * 1e3, 5) for r in repeats],
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": w["dtype"] if w["model"] == "vbpr" else "fp32", "data": "synthetic",
             "config": {"workload": "%s: %s k=%d d=%d D=%d, %d users x %d items per GPU, %s features, B=%d per GPU, %s"
@@ -517,7 +537,7 @@ def cpu_baseline_eager(w, tables, seconds):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        return float(loss)                                      # loss.numpy(): the reference's per-step host sync
+        return float(loss.detach())                             # loss.numpy(): the reference's per-step host sync
 
     step()                                                      # warm-up (allocations, Adam slots)
     n, t0 = 0, time.perf_counter()

@@ -17,6 +17,12 @@ def pytest_configure(config):
     os.environ.setdefault("BPRX_ADAM_LAZY", "1")
 
 
+# Reference-pinned host tests run in BOTH tiers: unmarked here (CPU container), and again as a gpu-marked twin on the GPU
+# box, so that the round-end `-m gpu` run exercises the golden index-stream / loader / metric fixtures against the shipped
+# libbprx.so and liboracle.so too.  Usage: @both_tiers + a `tier` argument.
+both_tiers = pytest.mark.parametrize("tier", ["cpu", pytest.param("gpu_box", marks=pytest.mark.gpu)])
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -14,11 +14,13 @@ from fashionvisualexpl_recommend_amd import _ffi, configs, synth
 from fashionvisualexpl_recommend_amd.dataset import DataLoader
 from fashionvisualexpl_recommend_amd.engine import HostSampler
 from fashionvisualexpl_recommend_amd.evaluator import Evaluator
+from conftest import both_tiers
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol():
+@both_tiers
+def test_library_exports_every_declared_symbol(tier):
     hdr = open(os.path.join(REPO, "include", "bprx.h")).read()
     declared = sorted(set(re.findall(r"BPRX_API[^;(]*?\b(bprx_\w+)\s*\(", hdr)))
     assert len(declared) >= 24
@@ -44,7 +46,8 @@ def _golden(golden_dir):
     return json.load(open(os.path.join(golden_dir, "golden.json")))
 
 
-def test_product_sampler_tiny_and_short(golden_dir):
+@both_tiers
+def test_product_sampler_tiny_and_short(golden_dir, tier):
     ds = json.load(open(os.path.join(golden_dir, "dataset_tiny.json")))
     for name, n in (("stream_tiny.npz", 32), ("stream_short.npz", 48)):
         g = np.load(os.path.join(golden_dir, name))
@@ -55,7 +58,8 @@ def test_product_sampler_tiny_and_short(golden_dir):
         assert np.array_equal(np.stack([u, i, j]), g["uij"])
 
 
-def test_product_sampler_c1_sha256(golden_dir):
+@both_tiers
+def test_product_sampler_c1_sha256(golden_dir, tier):
     gj = _golden(golden_dir)["c1"]
     tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
     u, i, j = HostSampler(tr, 2000).ref_stream(256, 5)
@@ -80,7 +84,8 @@ def tiny_on_disk(tmp_path, golden_dir):
     return ds
 
 
-def test_dataloader_mirror_reproduces_gap_shift(tiny_on_disk, golden_dir):
+@both_tiers
+def test_dataloader_mirror_reproduces_gap_shift(tiny_on_disk, golden_dir, tier):
     ds = tiny_on_disk
     data = DataLoader(Namespace(dataset="tiny", validation=True, batch_size=4, epochs=2))
     assert (data.num_users, data.num_items) == (6, 9)
@@ -102,7 +107,8 @@ class _NumpyModel:
 KEYS = ["hr_v", "auc_v", "p_v", "r_v", "ndcg_v", "hr_t", "auc_t", "p_t", "r_t", "ndcg_t"]
 
 
-def test_evaluator_mirror_tiny(tiny_on_disk, golden_dir, tmp_path, capsys):
+@both_tiers
+def test_evaluator_mirror_tiny(tiny_on_disk, golden_dir, tmp_path, capsys, tier):
     want = _golden(golden_dir)["eval_tiny"]
     sc = np.load(os.path.join(golden_dir, "eval_tiny_scores.npy"))
     data = DataLoader(Namespace(dataset="tiny", validation=True, batch_size=4, epochs=1))
@@ -116,7 +122,8 @@ def test_evaluator_mirror_tiny(tiny_on_disk, golden_dir, tmp_path, capsys):
     assert p.read_text() == open(os.path.join(golden_dir, "eval_tiny_recs.tsv")).read()
 
 
-def test_evaluator_mirror_c1(tmp_path, golden_dir):
+@both_tiers
+def test_evaluator_mirror_c1(tmp_path, golden_dir, tier):
     want = _golden(golden_dir)["eval_c1"]
     tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
     synth.write_dataset(str(tmp_path), "c1", tr, va, te, 2000)

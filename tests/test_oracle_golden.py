@@ -1,5 +1,5 @@
 """The oracle (oracle/bpr_oracle.c) against the fixtures produced by the reference's own sampler and
-Evaluator (tests/golden/gen_golden.py).  CPU only."""
+Evaluator (tests/golden/gen_golden.py).  Both tiers: on the CPU container and (gpu-marked twins) against the shipped binaries on the GPU box."""
 import hashlib
 import json
 import os
@@ -10,6 +10,7 @@ import pytest
 
 from fashionvisualexpl_recommend_amd import synth
 from oracle import oracle as orc
+from conftest import both_tiers
 
 
 def _golden(golden_dir):
@@ -39,7 +40,8 @@ def test_np_randint_matches_numpy_legacy(high):
 
 
 # ---- index stream vs the reference's DataLoader.all_triple_batches ----------------------------------------------
-def test_stream_tiny_bit_exact(golden_dir):
+@both_tiers
+def test_stream_tiny_bit_exact(golden_dir, tier):
     ds = _tiny(golden_dir)
     g = np.load(os.path.join(golden_dir, "stream_tiny.npz"))
     U, I, bs, ep = g["meta"].tolist()
@@ -48,7 +50,8 @@ def test_stream_tiny_bit_exact(golden_dir):
     assert np.array_equal(np.stack([u, i, j]), g["uij"])
 
 
-def test_stream_short_no_early_return(golden_dir):
+@both_tiers
+def test_stream_short_no_early_return(golden_dir, tier):
     """N < batch_size: (N//bs)*bs*epochs == 0, so dataset.py:109 never fires and all epochs are emitted."""
     ds = _tiny(golden_dir)
     g = np.load(os.path.join(golden_dir, "stream_short.npz"))
@@ -58,7 +61,8 @@ def test_stream_short_no_early_return(golden_dir):
     assert np.array_equal(np.stack([u, i, j]), g["uij"])
 
 
-def test_stream_c1_sha256(golden_dir):
+@both_tiers
+def test_stream_c1_sha256(golden_dir, tier):
     """BASELINE.md section 2 known answer: 99 840 triplets, sha256 f77db4ef..."""
     g = np.load(os.path.join(golden_dir, "stream_c1_head.npz"))
     gj = _golden(golden_dir)["c1"]
@@ -84,7 +88,8 @@ def test_stream_properties():
 KEYS = ["hr_v", "p_v", "r_v", "auc_v", "ndcg_v", "hr_t", "p_t", "r_t", "ndcg_t"]
 
 
-def test_eval_tiny_with_ties(golden_dir):
+@both_tiers
+def test_eval_tiny_with_ties(golden_dir, tier):
     ds = _tiny(golden_dir)
     want = _golden(golden_dir)["eval_tiny"]
     sc = np.load(os.path.join(golden_dir, "eval_tiny_scores.npy"))
@@ -95,7 +100,8 @@ def test_eval_tiny_with_ties(golden_dir):
     assert want["results"]["auc_t"] == want["results"]["auc_v"]
 
 
-def test_eval_c1(golden_dir):
+@both_tiers
+def test_eval_c1(golden_dir, tier):
     want = _golden(golden_dir)["eval_c1"]
     tr, va, te = synth.make_interactions(1000, 2000, per_user=22, seed=2024)
     sc = np.random.RandomState(want["score_seed"]).standard_normal((1000, 2000)).astype(np.float32)
