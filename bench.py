@@ -73,10 +73,6 @@ def parse():
     ap.add_argument("--no-dist-overlap", action="store_true",
                     help="N > 1, replicated mode: the round-1 order (ONE message [user rows | dE|dBp] after the whole local "
                          "step) instead of the user rows' all-gather travelling beside the backward projection")
-    ap.add_argument("--no-index-lookahead", action="store_true",
-                    help="draw each batch inside its own step (default: the NEXT step's batch is drawn at the start of a step "
-                         "and announced with bprx_hint_next_batch, so that its index pass runs on a side stream beside the "
-                         "running step's per-triplet kernels; still exactly one batch drawn and one step taken per timed step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-overlap", action="store_true",
                     help="draw each batch one step ahead on a side stream (measured on C2: 0.287 vs 0.280 ms/step without "
@@ -271,28 +267,7 @@ def main():
 
         prefetch(0)
 
-    # Default: one batch of look-ahead IN the stream -- step s first draws the batch of step s+1 into the other buffer set and
-    # names it to the library (bprx_hint_next_batch), then runs on its own batch.
-    from fashionvisualexpl_recommend_amd.dist import ReplicatedUserVBPR as _Rep
-    look = (batches is None and not pipe and not args.no_index_lookahead and (sharded is None or isinstance(sharded, _Rep)))
-    if look:
-        lbufs = (bufs, tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3)))
-        lstate = {"n": 0}
-
     def one_step(s):
-        if look:
-            slot = lstate["n"] & 1
-            if lstate["n"] == 0:
-                sampler.sample(B, out=lbufs[0])               # priming: the very first batch
-            lstate["n"] += 1
-            sampler.sample(B, out=lbufs[slot ^ 1])            # the NEXT step's batch
-            eng.hint_next_batch(*lbufs[slot ^ 1])
-            u, i, j = lbufs[slot]
-            if sharded is None:
-                eng.step(u, i, j, want_loss=False)
-            else:
-                sharded.step(u, i, j)
-            return
         if pipe:
             slot = state["n"] & 1
             state["n"] += 1
@@ -369,9 +344,7 @@ def main():
     prof = eng.profile_read()
     eng.profile(False)
     torch.cuda.synchronize()
-    # (fresh buffers: the look-ahead sets may hold a batch whose index pass has already run)
-    ub, ib, jb = (sampler.sample(B, out=tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3)))
-                  if batches is None else batches[0])
+    ub, ib, jb = sampler.sample(B, out=bufs) if batches is None else batches[0]
     loss = float((eng.step(ub, ib, jb) if sharded is None else sharded.step(ub, ib, jb, want_loss=True)).item())
     assert np.isfinite(loss), loss
 
@@ -450,7 +423,7 @@ def main():
                                     "device epoch walk (every positive once per epoch, user-grouped) + philox negative")
                                    + ", one batch per step inside the timed region%s (%d positives/user)"
                                    % (", drawn one step ahead on a side stream" if pipe else
-                                      (", drawn one step ahead in the stream and announced (bprx_hint_next_batch)" if look else ""),
+                                      "",
                                       args.pos_per_user)
                                    + (", Zipf(%.2f) item popularity, ids %s" % (args.zipf, args.zipf_ids) if args.zipf > 0 else ""))
                        if batches is None else "pre-generated uniform (u,i,j), resident"},

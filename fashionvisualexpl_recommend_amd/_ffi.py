@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPRX_LIB") or os.path.join(HERE, "libbprx.so")    # BPRX_LIB: A/B builds (scripts/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_EXPORT_USER_GRAD = 1
 FLAG_EXPORT_ITEM_GRAD = 2
 FLAG_DENSE_ALLREDUCE = 4
@@ -79,7 +79,6 @@ def lib():
         "bprx_step_begin": (C.c_int, [vp, vp, vp, vp, i64, vp]),
         "bprx_step_begin_sparse": (C.c_int, [vp, vp, vp, vp, i64, vp]),
         "bprx_step_begin_dense": (C.c_int, [vp, vp]),
-        "bprx_hint_next_batch": (C.c_int, [vp, vp, vp, vp, i64]),
         "bprx_dense_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "bprx_step_end": (C.c_int, [vp, vp, vp]),
         "bprx_step_project": (C.c_int, [vp, vp]),
@@ -119,7 +118,7 @@ def lib():
 
 EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_adam_is_lazy", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
-           "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts", "bprx_hint_next_batch",
+           "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",

@@ -28,21 +28,21 @@ static void graph_drop(bprx_handle *h) {
 }
 
 static bprx_handle::GraphSig graph_sig(const bprx_handle *h) {
-  return {h->list_slot, h->slist_slot, h->qs_slot, h->et_valid, h->p_valid, h->absmax_valid, h->W_dirty};
+  return {h->list_slot, h->slist_slot, h->qs_slot, h->seg_slot, h->et_valid, h->p_valid, h->absmax_valid, h->W_dirty};
 }
 static void graph_sig_apply(bprx_handle *h, const bprx_handle::GraphSig &g) {
-  h->list_slot = g.list_slot; h->slist_slot = g.slist_slot; h->qs_slot = g.qs_slot;
+  h->list_slot = g.list_slot; h->slist_slot = g.slist_slot; h->qs_slot = g.qs_slot; h->seg_slot = g.seg_slot;
   h->et_valid = g.et_valid; h->p_valid = g.p_valid; h->absmax_valid = g.absmax_valid; h->W_dirty = g.W_dirty;
 }
 static bool graph_sig_eq(const bprx_handle::GraphSig &a, const bprx_handle::GraphSig &b) {
-  return a.list_slot == b.list_slot && a.slist_slot == b.slist_slot && a.qs_slot == b.qs_slot && a.et_valid == b.et_valid &&
+  return a.list_slot == b.list_slot && a.slist_slot == b.slist_slot && a.qs_slot == b.qs_slot && a.seg_slot == b.seg_slot &&
+         a.et_valid == b.et_valid &&
          a.p_valid == b.p_valid && a.absmax_valid == b.absmax_valid && a.W_dirty == b.W_dirty;
 }
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next,
-                  h->alt.cntI, h->alt.seg_rank, h->alt.seg_ptr, h->alt.seg_cursor, h->alt.seg_lead};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_cnt, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->uslot_of, h->udone, h->uold, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -166,12 +166,15 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (vb && cfg->feat_dtype == BPRX_F_FP8 && h->bwd_variant < 8) h->bwd_variant = 26;                 // fp8: v3 only
     if (h->seg_policy && vb && cfg->feat_dtype != BPRX_F_FP32 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
     if (h->seg_policy) {
-      bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_ptr, I) == hipSuccess &&
-                 dalloc_zero(&h->seg_cursor, (size_t)2) == hipSuccess && dalloc_zero(&h->seg_lead, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->hot_done, I) == hipSuccess &&
-                 dalloc_zero((int2 **)&h->seg_ent, (size_t)2 * MB) == hipSuccess &&
-                 dalloc_zero(&h->alt.cntI, I) == hipSuccess && dalloc_zero(&h->alt.seg_rank, (size_t)2 * MB) == hipSuccess &&
-                 dalloc_zero(&h->alt.seg_ptr, I) == hipSuccess && dalloc_zero(&h->alt.seg_cursor, (size_t)2) == hipSuccess &&
-                 dalloc_zero(&h->alt.seg_lead, (size_t)2 * MB) == hipSuccess;
+      // chunk list: the owners' regions (one slot per item + 4 per owner, <= 1024 owners; a last partial range) + the overflow list
+      h->seg_lead_cap = (int64_t)(I + 8192 + 4 * 1024 + 2 * MB / 64 + 64 + 64);
+      h->seg_ent_cap = (int64_t)(6 * MB + 64 * 1024 + 2048);
+      bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_cnt, I) == hipSuccess &&
+                 dalloc_zero(&h->seg_ptr, I) == hipSuccess && dalloc_zero(&h->seg_cursor, (size_t)4) == hipSuccess &&
+                 dalloc_zero((int4 **)&h->seg_lead, (size_t)h->seg_lead_cap) == hipSuccess &&
+                 dalloc_zero(&h->hot_done, I) == hipSuccess && dalloc_zero((int2 **)&h->seg_ent, (size_t)h->seg_ent_cap) == hipSuccess &&
+                 dalloc_zero(&h->uslot_of, U) == hipSuccess && dalloc_zero(&h->udone, MB) == hipSuccess &&
+                 dalloc_zero(&h->uold, MB * (k + d)) == hipSuccess;
       if (!ok2) {
         snprintf(g_create_err, sizeof(g_create_err), "segment scratch allocation failed");
         free_scratch(h);
@@ -237,8 +240,6 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     }
   }
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_pf_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_pf_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
     snprintf(g_create_err, sizeof(g_create_err), "side stream / event creation failed");
@@ -249,13 +250,15 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   // BPRX_SIDE_STREAM (bit mask).  Measured on C2:
   //   1  the sparse optimizer pass beside the backward projection: SLOWER (0.385 vs 0.363 ms/step; both are
   //      bandwidth-bound and interfere: proj_bwd 93 -> 144 us, apply 35 -> 64 us)
-  //   2  the index pass beside the forward projection: no gain (0.2599 vs 0.2600; row_count 13.9 -> 24.9 us, proj_fwd +7 us)
+  //   (2, removed: the segment-mode index pass beside the forward projection.  Round 2's pass, 130 K memory-side count atomics:
+  //      0.2599 vs 0.2600 ms, both kernels stretched; round 3's k_index_seg, LDS counting: 0.238 vs 0.229 ms -- its 1024-thread
+  //      workgroups are only placed as the projection's one-workgroup-per-CU grid drains, and the join then waits for them)
   //   4  lazy Adam's catch-up (ALU-bound: correctly rounded sqrt / divide per replayed element and step) beside the
   //      HBM-bound forward projection of a streaming step: adam_tf23 0.330 -> 0.317 ms/step.  The default with adam_tf23.
   {
     const char *e = getenv("BPRX_SIDE_STREAM");
     h->side_mode = e ? atoi(e) : ((vb && cfg->optimizer == BPRX_OPT_ADAM_TF23 && h->adam_lazy) ? 4 : 0);
-    if (!h->side_mode && !h->seg_policy) { (void)hipStreamDestroy(h->side); h->side = nullptr; }   // (segment mode: index-pass prefetch)
+    if (!h->side_mode) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
   }
   {
     hipDeviceProp_t prop;
@@ -285,8 +288,6 @@ extern "C" int bprx_destroy(bprx_handle *h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->ev_pf_fork) (void)hipEventDestroy(h->ev_pf_fork);
-  if (h->ev_pf_done) (void)hipEventDestroy(h->ev_pf_done);
   if (h->prof_pending) { for (auto &r : *h->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } delete h->prof_pending; }
   if (h->prof_free) { for (auto e : *h->prof_free) (void)hipEventDestroy(e); delete h->prof_free; }
   delete h;
@@ -392,63 +393,6 @@ extern "C" int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32
   return bprx_launch_score(h, user, item, B, nullptr, 0, x, s);
 }
 
-static void idx_swap(bprx_handle *h) {                    // the other set of index-pass state becomes the current one
-  std::swap(h->cntI, h->alt.cntI); std::swap(h->seg_rank, h->alt.seg_rank); std::swap(h->seg_ptr, h->alt.seg_ptr);
-  std::swap(h->seg_cursor, h->alt.seg_cursor); std::swap(h->seg_lead, h->alt.seg_lead);
-}
-static bool seg_step(const bprx_handle *h, int64_t B) {   // would a step of B triplets run in segment mode (and not list mode)?
-  const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
-  const bool lm = vb && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
-  return !lm && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
-}
-
-// The index buffers of the step AFTER the coming one (already filled, or filled by work enqueued on the coming step's
-// stream before it): the coming step launches that batch's index pass on a side stream beside its own latency-bound
-// kernels, and the step after it -- called with exactly these pointers and B -- finds the pass done.  A hint that is not
-// followed (other pointers, another B, a step that does not run in segment mode) costs one small memset.
-extern "C" int bprx_hint_next_batch(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B) {
-  if (!h) return BPRX_E_INVALID;
-  if (!user || !pos || !neg || B <= 0 || B > h->cfg.max_batch) BPRX_FAIL(h, BPRX_E_INVALID, "hint_next_batch: bad arguments");
-  h->hint_u = user; h->hint_i = pos; h->hint_j = neg; h->hint_B = B;
-  return BPRX_OK;
-}
-
-// where a hinted next-batch index pass is forked: 0 (default) before k_triplet_grad, 1 (BPRX_PF_AT=1) before the backward projection
-static int prefetch_fork_point() {
-  static const int at = getenv("BPRX_PF_AT") ? atoi(getenv("BPRX_PF_AT")) : 0;
-  return at;
-}
-
-static int launch_prefetch(bprx_handle *h, hipStream_t s) {
-  // the NEXT batch's index pass (bprx_hint_next_batch), from here on beside this step's per-triplet / per-item kernels --
-  // latency-bound on both sides, so they overlap (beside the HBM-bound forward projection the same pass only stretched both)
-  h->pf_zero_w = false;
-  int rc = BPRX_OK;
-  const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
-  if (h->hint_u) {
-    const int32_t *nu = h->hint_u, *ni = h->hint_i, *nj = h->hint_j;
-    const int64_t nB = h->hint_B;
-    h->hint_u = nullptr;
-    if (h->side && h->alt.cntI && seg_step(h, nB) && !h->prof) {
-      BPRX_HIP(h, hipEventRecord(h->ev_pf_fork, s));
-      BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_pf_fork, 0));
-      const int lm = h->list_mode, im = h->item_mode;
-      h->list_mode = 0; h->item_mode = 1;
-      idx_swap(h);
-      h->pf_launching = true;
-      rc = bprx_launch_index_pass(h, nu, ni, nj, nB, h->side);
-      h->pf_launching = false;
-      idx_swap(h);
-      h->list_mode = lm; h->item_mode = im;
-      if (rc) return rc;
-      BPRX_HIP(h, hipEventRecord(h->ev_pf_done, h->side));
-      h->pf_u = nu; h->pf_i = ni; h->pf_j = nj; h->pf_B = nB; h->pf_done = true;
-      h->pf_zero_w = vb && h->cfg.feat_dtype != BPRX_F_FP32;     // its bf16 W image: re-zeroed by this step's dense update
-    }
-  }
-  return BPRX_OK;
-}
-
 // First half of bprx_step_begin: index pass, item projections, per-triplet gradients.  Afterwards the USER-side gradients
 // of the batch are final (staging tables with BPRX_FLAG_EXPORT_USER_GRAD): a replicated-user step packs and all-gathers
 // them while bprx_step_begin_dense (item rows, W, dE|dBp = F^T W) is still running.
@@ -464,21 +408,6 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
   h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
   h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
   h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
-  // the previous step may have run THIS batch's index pass already (bprx_hint_next_batch)
-  bool idx_ready = false;
-  h->idx_hinted = false;
-  if (h->pf_done) {
-    h->pf_done = false;
-    BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_pf_done, 0));
-    if (h->pf_u == user && h->pf_i == pos && h->pf_j == neg && h->pf_B == B && h->item_mode && !h->proj_fresh) {
-      idx_swap(h);
-      idx_ready = true;
-      h->idx_hinted = true;
-    } else {
-      // not followed: the pass's item counts would never be consumed (k_item_seg resets what it walks)
-      BPRX_HIP(h, hipMemsetAsync(h->alt.cntI, 0, (size_t)h->cfg.num_items * sizeof(int32_t), s));
-    }
-  }
   float lr_t = h->cfg.lr;
   bool catchup_aside = false;     // BPRX_SIDE_STREAM & 4: the (ALU-bound) lazy-Adam catch-up runs beside the (HBM-bound) projection
   if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
@@ -493,12 +422,10 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
       if (!catchup_aside && (rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, s))) return rc;
     }
   }
-  const bool fork_index = !idx_ready && vb && !h->list_mode && !h->proj_fresh && h->side && (h->side_mode & 2);
-  if (fork_index || catchup_aside) {                       // work that does not depend on P, beside the projection
+  if (catchup_aside) {                                     // work that does not depend on P, beside the projection
     BPRX_HIP(h, hipEventRecord(h->ev_fork, s));
     BPRX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    if (catchup_aside && (rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, h->side))) return rc;
-    if (fork_index && (rc = bprx_launch_index_pass(h, user, pos, neg, B, h->side))) return rc;
+    if ((rc = bprx_launch_adam_catchup(h, user, pos, neg, B, lr_t, h->side))) return rc;
     BPRX_HIP(h, hipEventRecord(h->ev_join, h->side));
   }
   if (h->list_mode) {
@@ -513,9 +440,8 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
     if (!h->p_valid && (rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;  // every item
   }
   h->proj_fresh = false;
-  if (fork_index || catchup_aside) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
-  if (!fork_index && !idx_ready && !h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
-  if (prefetch_fork_point() == 0 && (rc = launch_prefetch(h, s))) return rc;
+  if (catchup_aside) BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
+  if (!h->list_mode && (rc = bprx_launch_index_pass(h, user, pos, neg, B, s))) return rc;
   if ((rc = bprx_launch_triplet_grad(h, user, pos, neg, B, s))) return rc;
   h->pending_B = B;
   h->pending_stage = 1;
@@ -533,7 +459,6 @@ extern "C" int bprx_step_begin_dense(bprx_handle *h, void *stream) {
   const float lr_t = h->pend_lr;
   int rc;
   if ((rc = bprx_launch_item_seg(h, pos, neg, B, lr_t, s))) return rc;                  // item rows + W, no float atomics
-  if (prefetch_fork_point() == 1 && (rc = launch_prefetch(h, s))) return rc;
   // sparse tables are final now: their optimizer pass does not depend on the dense all-reduce, nor on the backward
   // projection -- with VBPR it runs on the side stream beside it
   if (vb && h->side && (h->side_mode & 1)) {
@@ -647,7 +572,7 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   // when that pays).  Not for adam (lr_t changes every step), not while per-kernel profiling is on, not on the legacy
   // default stream (cannot be captured): those take the plain path.
   const bool can_graph = (h->graph_mode == 1 || (h->graph_mode == 2 && B <= 8192)) && h->cfg.optimizer == BPRX_OPT_SGD &&
-                         !h->prof && stream != nullptr && !h->side_mode && !h->hint_u && !h->pf_done && h->bound && B > 0 && B <= h->cfg.max_batch && user && pos &&
+                         !h->prof && stream != nullptr && !h->side_mode && h->bound && B > 0 && B <= h->cfg.max_batch && user && pos &&
                          neg && !h->proj_fresh && !h->pending_B;
   if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
   hipStream_t s = (hipStream_t)stream;

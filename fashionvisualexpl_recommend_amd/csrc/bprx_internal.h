@@ -56,22 +56,29 @@ struct bprx_handle {
   int seg_policy;                 // 0 never, 1 per step (2B >= I), 2 always (env BPRX_ITEM_MODE)
   int item_mode;                  // this step: 1: item-side gradients by per-item occurrence segments (k_item_seg), 0: global
                                   //    float atomics into the staging tables + claim-apply
+  // Occurrence segments (segment mode), built by ONE launch of k_index_seg (bprx_sparse.hip): workgroup w OWNS the item
+  // range [w*R, (w+1)*R): it scans all 2B item occurrences, counts and ranks those of its items in LDS (no global atomics),
+  // prefix-sums its counts, reserves the entries with one cursor atomic and lists its items' chunks for k_item_seg.
   int32_t *seg_rank;              // [2 * max_batch] rank of occurrence (role*B + b) among its item's occurrences
-  int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent (valid for items of the current batch)
-  int32_t *seg_cursor;            // [2] bump allocator of segments; number of chunk leaders listed in seg_lead
-  int32_t *seg_lead;              // [2 * max_batch] occurrences (role*B + b) that lead a chunk: k_item_seg's work list
-  // Second set of the index-pass state (segment mode): bprx_hint_next_batch names the NEXT step's index buffers and the
-  // running step launches that batch's index pass (k_row_count + k_seg_alloc: latency-bound, 21 us at C2) on the side stream
-  // beside its own latency-bound kernels, into this set; the next step swaps the sets instead of running the pass.
-  struct IdxAlt { int32_t *cntI, *seg_rank, *seg_ptr, *seg_cursor, *seg_lead; } alt;
-  const int32_t *hint_u, *hint_i, *hint_j; int64_t hint_B;          // bprx_hint_next_batch (consumed by the next step)
-  const int32_t *pf_u, *pf_i, *pf_j; int64_t pf_B; bool pf_done;    // index pass of that batch in flight / finished in `alt`
-  bool idx_hinted;                // the running step uses index state that a hint computed ahead of it (offsets are range-checked)
-  bool pf_launching;              // bprx_launch_index_pass runs for the prefetched batch (no W-image zeroing there)
-  bool pf_zero_w;                 // this step's k_dense_update re-zeroes the bf16 W image (the prefetched pass could not)
-  hipEvent_t ev_pf_fork, ev_pf_done;
+  int32_t *seg_cnt;               // [I] occurrences of the item in this batch (rewritten for every item by each index pass)
+  int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent
+  int32_t *seg_cursor;            // [4] two (entries, listed chunks) cursor pairs used by alternate steps: an index pass
+                                  //     clears the pair of the NEXT step
+  int seg_slot;                   // cursor pair of the next segment-mode step
+  int seg_cur_slot;               // cursor pair of the step in flight
+  void *seg_lead;                 // int4 [seg_lead_cap] {item, first entry, entries of the chunk, entries of the item}: k_item_seg's work list
+  int64_t seg_lead_cap;
+  int seg_lead_over;              // this step: slots of the owners' regions (the overflow list follows)
+  int64_t seg_ent_cap;            // entries allocated in seg_ent
+  // user side of a segment-mode sgd step: the batch's users are finished inside k_triplet_seg (run-segmented sums in LDS;
+  // users whose occurrences span workgroups meet in the staging rows and the workgroup that arrives last finishes them), so
+  // there is no apply pass.  k_item_seg, which needs the PRE-update user rows afterwards, reads them from uold.
+  int32_t *uslot_of;              // [U] batch position of the user's first run head = the user's slot (valid for users of the batch)
+  int32_t *udone;                 // [max_batch] occurrences of the slot's user that have been added (all-zero between steps)
+  float *uold;                    // [max_batch][k + d] pre-update [gamma_u | theta_u] of the slot's user
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
-  void *seg_ent;                  // [2 * max_batch] 8-byte entries {user | role << 31, g_b}
+  void *seg_ent;                  // [seg_ent_cap] 8-byte entries {user or user slot | role << 31, g_b}: the owners' regions (twice
+                                  //     the expected occupancy each) + 2 * max_batch for the owners that overflow theirs
   // touched-item list (sparse batches, 2B < I): both projections run over the batch's DISTINCT items only
   int list_policy;                // 0 never, 1 per step (2B < I), 2 always (env BPRX_LIST_MODE)
   int list_mode;                  // this step
@@ -101,14 +108,14 @@ struct bprx_handle {
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
   bool side_pending;
-  int side_mode;                  // BPRX_SIDE_STREAM: 1 = sparse optimizer pass beside proj_bwd, 2 = index pass beside proj_fwd
+  int side_mode;                  // BPRX_SIDE_STREAM bit mask: 1 = sparse optimizer pass beside proj_bwd, 4 = lazy-Adam catch-up beside proj_fwd
   // hipGraph of the whole sgd step (bprx_step): captured on first use, replayed while the call's arguments repeat
   // hipGraphs of the whole sgd step (bprx_step): captured when a call repeats the previous call's arguments, replayed while
   // they keep repeating.  A captured launch sequence depends on the host-side state below (cursor slots that alternate from
   // step to step, validity of the derived images), so an exec is stored with the state it was captured in and the state
   // it leaves, and is replayed only from the same state; a steady training loop alternates between two execs.
   int graph_mode;                 // env BPRX_GRAPH: 0 (default) = never, 1 = always, 2 = small steps only (B <= 8192)
-  struct GraphSig { int list_slot, slist_slot, qs_slot; bool et_valid, p_valid, absmax_valid, W_dirty; };
+  struct GraphSig { int list_slot, slist_slot, qs_slot, seg_slot; bool et_valid, p_valid, absmax_valid, W_dirty; };
   struct GraphEnt { hipGraphExec_t exec; GraphSig in, out; };
   GraphEnt graph_ents[4];
   int graph_n;

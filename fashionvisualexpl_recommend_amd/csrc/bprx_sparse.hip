@@ -27,7 +27,6 @@ struct SparseArgs {
   int32_t *errflag;
   int U, I, k, d, PS;
   float reg;
-  int item_atomics;   // 1: item-side gradients by global atomics (staging tables); 0: occurrence segments + k_item_seg
   // exclusive-row fast path (sgd): multiplicity of every row in the batch; rows used by exactly one triplet are
   // updated in place by that triplet's group (6 row transfers per triplet, no staging, no atomics, no apply pass)
   int32_t *cntU, *cntI;
@@ -35,15 +34,16 @@ struct SparseArgs {
   int fast;                       // any fast side on (k_apply_sgd then resets the counters)
   int fastU, fastI;               // per side: off for rows whose gradients are exported (staging rows)
   float lr;
-  // occurrence segments (item_atomics == 0)
-  const int32_t *seg_lead, *seg_nlead;   // chunk leaders (occurrence numbers) and their count
-  int seg_guard;             // this step runs on index state computed ahead of it (bprx_hint_next_batch): offsets are checked
-  int seg_cap;               // entries allocated (2 * max_batch): offsets are clamped to it, so that index state that does not
-                             // belong to the batch (a bprx_hint_next_batch whose buffers were changed afterwards) cannot
-                             // address outside the allocation
+  // occurrence segments (segment mode; built by k_index_seg)
+  const int4 *seg_lead;      // k_item_seg's work list: {item, first entry, entries of the chunk, entries of the item}
+  const int32_t *seg_nlead;  // its length (device)
+  int seg_lead_cap, seg_lead_over;   // slots in all; slots of the owners' regions (the overflow list follows)
+  int seg_cap;               // entries allocated (2 * max_batch): entry offsets are clamped to it
   const int32_t *seg_rank;   // [2B] rank of occurrence (role*B + b) within its item
   const int32_t *seg_ptr;    // [I]  first entry of the item's segment
-  int2 *seg_ent;             // [2B] {user | role << 31, g_b}
+  int2 *seg_ent;             // [2B] {user key | role << 31, g_b}; the key indexes the rows below
+  const float *uG, *uT;      // PRE-update user rows as k_item_seg gathers them: the tables (key = user id), or the batch's
+  int usG, usT;              //   uold rows (key = user slot; k_triplet_seg mode 0); row strides in floats
   int32_t *hot_done;         // [I]  finished chunks of a hot item (k_item_seg's last-finisher hand-off), all-zero between steps
   // shared-row list (sgd fast path): the occurrence that marks a shared row first appends it (kind << 30 | row); the apply
   // pass then walks this list instead of every occurrence of the batch
@@ -126,30 +126,23 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v) {
 
 __device__ __forceinline__ int clamp_quiet(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }   // as clamp_idx()
 
-// Multiplicity of every user / item row in the batch (an item counts in both roles).  One thread per triplet, three
-// int atomics (non-returning; returning on the item side when `rank` is wanted: the value returned is the rank of the
-// occurrence among its item's occurrences).  The counters are reset by k_apply_sgd (users) / k_item_seg (items).
+// Multiplicity of every user / item row in the batch (an item counts in both roles), for the atomic-staging paths (sparse
+// batches: exclusive-row fast path, touched-item list).  One thread per triplet, three int atomics.  The counters are reset
+// by k_apply_sgd[_list] / k_triplet_grad / k_dense_update.  (Segment mode has its own index pass: k_index_seg.)
 __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ user, const int32_t *__restrict__ pos,
                                                    const int32_t *__restrict__ neg, int64_t B, int U, int I,
                                                    int32_t *__restrict__ cntU, int32_t *__restrict__ cntI, int doU, int doI,
-                                                   int32_t *__restrict__ rank, int32_t *__restrict__ seg_cursor,
-                                                   uint4 *__restrict__ zero16, size_t nzero16,
                                                    int32_t *__restrict__ ilist, int32_t *__restrict__ ilist_n, int ilist_cap,
                                                    int32_t *__restrict__ slist, int32_t *__restrict__ slist_n, int slist_cap) {
-  // housekeeping that would otherwise be two hipMemsetAsync launches (5-6 us each on the trace): the segment cursor, and
-  // the bf16 W image of the previous step (consumed by its backward projection), re-zeroed for k_item_seg
-  if (seg_cursor && blockIdx.x == 0 && threadIdx.x == 0) { seg_cursor[0] = 0; seg_cursor[1] = 0; }
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nzero16; e += (size_t)gridDim.x * 256)
-    zero16[e] = make_uint4(0, 0, 0, 0);
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = b < B;
   const int u = valid ? clamp_quiet(user[b], U) : 0, i = valid ? clamp_quiet(pos[b], I) : 0, j = valid ? clamp_quiet(neg[b], I) : 0;
-  if (!rank && !ilist && !slist) {
+  if (!ilist && !slist) {
     if (valid && doU) atomicAdd(cntU + u, 1);
     if (valid && doI) { atomicAdd(cntI + i, 1); atomicAdd(cntI + j, 1); }
     return;
   }
-  if (!rank) {
+  {
     // The count atomics RETURN here (three independent ones per thread, in flight together) and the value tells what else
     // this occurrence has to do:
     //   ilist (list mode, sparse VBPR batches): it found its item's count at 0 -> it appends the item to the list of the
@@ -201,100 +194,14 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
     if (sj) { if (at1 < slist_cap) slist[at1] = j | (1 << 30); }
     return;
   }
-  if (valid && doU) atomicAdd(cntU + u, 1);
-  // Ranks: the workgroup's 512 occurrences are first counted per item in an LDS hash table (LDS atomics), then ONE global
-  // returning atomic per distinct item and workgroup fetches the base rank.  A hot item (Zipf popularity: thousands of
-  // occurrences per batch) then costs one same-address global atomic per workgroup instead of one per occurrence
-  // (~15 ns each, serialised: measured 95 us for this kernel at Zipf(1.0) without the table).
-  constexpr int HS = 1024;
-  __shared__ int hkey[HS], hcnt[HS], hbase[HS];
-  for (int t = threadIdx.x; t < HS; t += 256) { hkey[t] = -1; hcnt[t] = 0; }
-  __syncthreads();
-  int slot_i = 0, slot_j = 0, loc_i = 0, loc_j = 0;
-  if (valid) {
-    int sl = (int)(((unsigned)i * 2654435761u) >> 22);                       // 10-bit multiplicative hash
-    for (;;) {
-      const int prev = atomicCAS(&hkey[sl], -1, i);
-      if (prev == -1 || prev == i) break;
-      sl = (sl + 1) & (HS - 1);
-    }
-    slot_i = sl; loc_i = atomicAdd(&hcnt[sl], 1);
-    sl = (int)(((unsigned)j * 2654435761u) >> 22);
-    for (;;) {
-      const int prev = atomicCAS(&hkey[sl], -1, j);
-      if (prev == -1 || prev == j) break;
-      sl = (sl + 1) & (HS - 1);
-    }
-    slot_j = sl; loc_j = atomicAdd(&hcnt[sl], 1);
-  }
-  __syncthreads();
-  {
-    // one returning atomic per distinct item of the workgroup: the (up to) four of a thread are all requested before the
-    // first result is stored (one after the other they were four memory round trips)
-    int hk[HS / 256], hb[HS / 256];
-#pragma unroll
-    for (int q = 0; q < HS / 256; ++q) hk[q] = hkey[threadIdx.x + q * 256];
-#pragma unroll
-    for (int q = 0; q < HS / 256; ++q) hb[q] = hk[q] >= 0 ? atomicAdd(cntI + hk[q], hcnt[threadIdx.x + q * 256]) : 0;
-#pragma unroll
-    for (int q = 0; q < HS / 256; ++q) hbase[threadIdx.x + q * 256] = hb[q];
-  }
-  __syncthreads();
-  if (valid) {
-    rank[b] = hbase[slot_i] + loc_i;
-    rank[B + b] = hbase[slot_j] + loc_j;
-  }
-}
-
-// Segment allocation: the rank-0 occurrence of every item of the batch reserves cnt[item] entries.  One thread per
-// occurrence; the reservations of a 1024-thread workgroup are prefix-summed (shuffles + LDS) and taken with ONE atomic
-// on the cursor (same-address returning atomics cost ~15 ns each: one per wave measured 32 us for 2K waves).
-__global__ __launch_bounds__(1024) void k_seg_alloc(const int32_t *__restrict__ pos, const int32_t *__restrict__ neg,
-                                                    int64_t B, int I, const int32_t *__restrict__ rank,
-                                                    const int32_t *__restrict__ cntI, int32_t *__restrict__ seg_ptr,
-                                                    int32_t *__restrict__ cursor, int32_t *__restrict__ lead) {
-  __shared__ int wsum[16], lsum[16];
-  __shared__ int wbase, lbase;
-  const int64_t job = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int item = 0, c = 0;
-  bool leads = false;                            // this occurrence leads a chunk of its item's segment (rank 0, CAP, 2 CAP, ...)
-  if (job < 2 * B) {
-    item = clamp_quiet(job < B ? pos[job] : neg[job - B], I);
-    const int rk = rank[job];
-    if (rk == 0) c = cntI[item];
-    leads = rk % SEG_CAP == 0;
-  }
-  int incl = c;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  const unsigned long long lb = __ballot(leads);
-  if (lane == 63) wsum[w] = incl;
-  if (lane == 0) lsum[w] = __popcll(lb);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0, l = 0;
-    for (int q = 0; q < 16; ++q) { const int v = wsum[q]; wsum[q] = t; t += v; const int lv = lsum[q]; lsum[q] = l; l += lv; }
-    wbase = t ? atomicAdd(cursor, t) : 0;
-    lbase = l ? atomicAdd(cursor + 1, l) : 0;
-  }
-  __syncthreads();
-  if (c) seg_ptr[item] = wbase + wsum[w] + incl - c;
-  // the chunk leaders, compacted: k_item_seg runs one lane group per listed occurrence instead of one per occurrence with
-  // two thirds of the groups leaving at once (C2: 46 K leaders of 131 K occurrences)
-  if (leads) lead[lbase + lsum[w] + __popcll(lb & ((1ull << lane) - 1ull))] = (int32_t)job;
 }
 
 // One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
 // (or, for rows no other triplet of the batch uses, the finished sgd update straight into the table).
-// SEG: the launch is in segment mode (a.item_atomics == 0); a compile-time flag so that the register-sourced backward of
-// the user side (below) costs the atomic-mode instantiation nothing.
-template <int G, bool VEC, bool SEG>
-__device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int32_t *__restrict__ user,
-                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
+// The atomic-staging form (sparse batches, BPRMF shards, exported gradients); segment mode runs k_triplet_seg instead.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
+                                                      const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   // `full`: every lane group of this workgroup has a triplet (all but the last workgroup): only then may the workgroup
@@ -311,15 +218,6 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   const float bi = a.Bi[i], bj = a.Bi[j];
   int mulU = 0, mulI = 0, mulJ = 0;                       // (ONE uniform branch: a load under a branch of its own is waited for on the spot)
   if (a.fastU | a.fastI) { mulU = a.cntU[u]; mulI = a.cntI[i]; mulJ = a.cntI[j]; }
-  int rkI = 0, rkJ = 0, spI = 0, spJ = 0;
-  if (!a.item_atomics) {
-    rkI = a.seg_rank[b]; rkJ = a.seg_rank[B + b]; spI = a.seg_ptr[i]; spJ = a.seg_ptr[j];
-    spI += rkI; spJ += rkJ; rkI = 0; rkJ = 0;             // entry slots
-    if (a.seg_guard) {
-      const unsigned top = (unsigned)a.seg_cap - 1u;
-      spI = (int)((unsigned)spI < top ? (unsigned)spI : top); spJ = (int)((unsigned)spJ < top ? (unsigned)spJ : top);
-    }
-  }
   const float *gu = a.Gu + (size_t)u * k, *gi = a.Gi + (size_t)i * k, *gj = a.Gi + (size_t)j * k;
   const float *tu = d ? a.Tu + (size_t)u * d : nullptr;
   const float *Pi = d ? a.P + (size_t)i * a.PS : nullptr, *Pj = d ? a.P + (size_t)j * a.PS : nullptr;
@@ -377,32 +275,22 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
   // exclusive rows: nobody else reads or writes them in this batch, so the in-place update is batch-synchronous
   const bool exU = a.fastU && mulU == 1;
   const bool exI = a.fastI && mulI == 1, exJ = a.fastI && mulJ == 1;               // i == j gives count 2: shared
-  // item side: global atomics, or (segments) one 8-byte entry per occurrence (hot items are chunked later)
-  const bool iaI = a.item_atomics, iaJ = a.item_atomics;
   if (lane == 0) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
     if (a.use_list) {
       // shared rows were listed for the apply pass by k_row_count (the occurrence that found the count at one); exclusive
       // rows (finished by this group alone) reset their multiplicity here -- nobody else looks at it
       if (exU) a.cntU[u] = 0;
-      if (iaI) {
-        if (exI) { a.wBi[i] = bi - lr * (g + r2 * bi); a.cntI[i] = 0; }
-        else atomicAdd(a.dBi + i, g + r2 * bi);
-      } else a.seg_ent[spI + rkI] = make_int2(u, __float_as_int(g));
-      if (iaJ) {
-        if (exJ) { a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj); a.cntI[j] = 0; }
-        else atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
-      } else a.seg_ent[spJ + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
+      if (exI) { a.wBi[i] = bi - lr * (g + r2 * bi); a.cntI[i] = 0; }
+      else atomicAdd(a.dBi + i, g + r2 * bi);
+      if (exJ) { a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj); a.cntI[j] = 0; }
+      else atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj);
     } else {
-    if (!exU) a.flagU[u] = 1u;
-    if (iaI) {
+      if (!exU) a.flagU[u] = 1u;
       if (exI) a.wBi[i] = bi - lr * (g + r2 * bi);
       else { atomicAdd(a.dBi + i, g + r2 * bi); a.flagI[i] = 1u; }
-    } else a.seg_ent[spI + rkI] = make_int2(u, __float_as_int(g));
-    if (iaJ) {
       if (exJ) a.wBi[j] = bj - lr * (-g + (r2 * 0.1f) * bj);
       else { atomicAdd(a.dBi + j, -g + (r2 * 0.1f) * bj); a.flagI[j] = 1u; }
-    } else a.seg_ent[spJ + rkJ] = make_int2((int)((unsigned)u | 0x80000000u), __float_as_int(g));
     }
   }
   // ---- backward: per-occurrence gradients from the same pre-update rows (L1/L2 hits) ----
@@ -435,24 +323,22 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
     __syncthreads();
     wgc = s_u[0] >= 0 && s_u[0] == s_u[1] && s_u[1] == s_u[2] && s_u[2] == s_u[3];
   }
-  // Segment mode with a workgroup-wide user (the common case in epoch order): nothing of the item side is left to do
-  // here and the user-row gradient goes to LDS, so the backward pass needs NO second read of the rows in the
-  // lane = element layout -- it is formed from the forward pass's registers (16 B per lane) and summed across the groups.
-  // (wide rows only, G >= 32: at G = 16 the 27 four-byte re-reads are L1 hits and cheaper than the extra live registers:
-  //  measured 38 -> 40 us on C2, 62 -> 55 us at k = d = 128, 106 -> 84 us at k = d = 256)
-  // ... and, on the atomic path (sparse batches), also the finished rows of EXCLUSIVE items: one 16-B store per lane from
-  // the registers instead of four 4-B re-reads and four 4-B stores (C3 shard: ~88 % of the item rows).
+  // BPRMF with a workgroup-wide user (the common case in epoch order): the user-row gradient goes to LDS, so the backward
+  // pass needs NO second read of the rows in the lane = element layout -- it is formed from the forward pass's registers
+  // (16 B per lane) and summed across the groups (wide rows only, G >= 32) ...
+  // ... and so are the finished rows of EXCLUSIVE items: one 16-B store per lane from the registers instead of four 4-B
+  // re-reads and four 4-B stores (C3 shard: ~88 % of the item rows).
   const bool regs_ok = G >= 32 && VEC && k <= 4 * G && d <= 4 * G;
-  const bool from_regs = regs_ok && wgc && (SEG ? !iaI : d == 0);   // (atomic path with d > 0: the W rows are written below)
+  const bool from_regs = regs_ok && wgc && d == 0;        // (d > 0: the W rows are written by the element loop below)
   // (stored AFTER the element loop, which still re-reads the pre-update item rows for the user-side gradient)
-  const bool regI = !SEG && regs_ok && a.reg_items && d == 0 && iaI && exI, regJ = !SEG && regs_ok && a.reg_items && d == 0 && iaJ && exJ;
+  const bool regI = regs_ok && a.reg_items && d == 0 && exI, regJ = regs_ok && a.reg_items && d == 0 && exJ;
   // ... and the gradients of SHARED item rows on that path (atomic staging): formed from the same registers and turned into
   // the lane = element layout of the atomics (full 128-B requests) through a per-group LDS row, instead of sending the whole
   // wave through the element loop below because one of its four item rows is shared (C3 shard: 12 % of the rows, 40 % of the
   // waves).  Only where the loop would otherwise be skipped (user side from registers).
-  const bool shI = !SEG && regs_ok && wgc && a.reg_items && d == 0 && iaI && !exI;
-  const bool shJ = !SEG && regs_ok && wgc && a.reg_items && d == 0 && iaJ && !exJ;
-  const bool doneI = !iaI || regI || shI, doneJ = !iaJ || regJ || shJ;   // item rows with nothing to do in the element loop below
+  const bool shI = regs_ok && wgc && a.reg_items && d == 0 && !exI;
+  const bool shJ = regs_ok && wgc && a.reg_items && d == 0 && !exJ;
+  const bool doneI = regI || shI, doneJ = regJ || shJ;   // item rows with nothing to do in the element loop below
   if (from_regs) {
     const int c = lane * 4;
     float4 du = make_float4(g * (fq.x - fr.x) + r2 * fp.x, g * (fq.y - fr.y) + r2 * fp.y, g * (fq.z - fr.z) + r2 * fp.z,
@@ -493,7 +379,7 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
       if (exJ) pj[c] = r - lr * dj; else atomicAdd(aj + c, dj);
     }
   }
-  if (!SEG && regs_ok && __any(shI || shJ)) {             // wave-uniform entry; the LDS row belongs to this lane group alone
+  if (regs_ok && __any(shI || shJ)) {             // wave-uniform entry; the LDS row belongs to this lane group alone
     __shared__ __attribute__((aligned(16))) float s_tr[256 / G][4 * G];
     float *row = s_tr[threadIdx.x / G];
     const int c4 = lane * 4;
@@ -548,8 +434,8 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
         } else atomicAdd(at + c, dt);
       }
       // W is all-zero before the step: a sole contributor stores
-      if (iaI) { if (exI) wi[c] = g * p; else atomicAdd(wi + c, g * p); }
-      if (iaJ) { if (exJ) wj[c] = -g * p; else atomicAdd(wj + c, -g * p); }
+      if (exI) wi[c] = g * p; else atomicAdd(wi + c, g * p);
+      if (exJ) wj[c] = -g * p; else atomicAdd(wj + c, -g * p);
     }
   }
   if (wgc) {                                              // workgroup-uniform
@@ -560,17 +446,6 @@ __device__ __forceinline__ void triplet_grad_body(const SparseArgs &a, const int
       atomicAdd(e < k ? a.dGu + (size_t)uw * k + e : a.dTu + (size_t)uw * d + (e - k), sum);
     }
   }
-}
-
-template <int G, bool VEC>
-__global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
-                                                      const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
-  triplet_grad_body<G, VEC, false>(a, user, pos, neg, B);
-}
-template <int G, bool VEC>
-__global__ __launch_bounds__(256) void k_triplet_grad_seg(SparseArgs a, const int32_t *__restrict__ user,
-                                                          const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
-  triplet_grad_body<G, VEC, true>(a, user, pos, neg, B);
 }
 
 // sgd: one group per occurrence; the first to claim a touched row applies  p -= lr*dG  and re-zeroes dG.
@@ -974,14 +849,9 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
                                                       uint16_t *__restrict__ EtF, const int32_t *__restrict__ ilist,
                                                       const int32_t *__restrict__ ilist_n, int32_t *__restrict__ ilist_n_next,
                                                       int bound, float *__restrict__ W, int32_t *__restrict__ cnt_reset,
-                                                      uint32_t *__restrict__ absmax_out, uint4 *__restrict__ zero16,
-                                                      size_t nzero16) {
+                                                      uint32_t *__restrict__ absmax_out) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[DU_KB][288];   // PS <= 272
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  // the bf16 W image, consumed by this step's backward projection, back to zero for the next step's k_item_seg (when that
-  // step's index pass -- which does it otherwise -- has already run: bprx_hint_next_batch)
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nzero16; e += (size_t)gridDim.x * 256)
-    zero16[e] = make_uint4(0, 0, 0, 0);
   if (ilist_n_next && blockIdx.x == 0 && threadIdx.x == 0) *ilist_n_next = 0;
   if (ilist) {
     int n = *ilist_n;
@@ -1152,6 +1022,324 @@ __global__ __launch_bounds__(256) void k_score_block(SparseArgs a, int u0, int u
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Segment-mode index pass in ONE launch (round 3; it replaced the returning count atomics of k_row_count -- 130 K memory-side
+// atomics, 13 us at C2 -- and the separate k_seg_alloc launch, 8-10 us).
+// Owner workgroups: workgroup w OWNS the items [w*R, (w+1)*R).  It reads all 2B item occurrences of the batch (16 B per lane,
+// 512 KB at B = 65 536, served by the XCD's L2 after the first workgroup has pulled it), and for the occurrences of ITS items
+// counts and ranks in LDS -- every occurrence of an item meets in one workgroup, so no global atomic is needed and the count
+// is final when the scan ends.  The workgroup then prefix-sums its counts, reserves its items' entries with ONE atomic on the
+// entry cursor, writes seg_cnt / seg_ptr for every item of its range, lists the chunks of its touched items for k_item_seg
+// ({item, first entry, entries of the chunk, entries of the item}: that kernel needs no second look-up) and zeroes the bf16 W
+// rows of its UNTOUCHED items (7 % of the rows at C2, instead of the whole 8-MB image).
+// User workgroups (blockIdx < nuser, sgd segment steps): one thread per triplet; the first lane of every run of equal users
+// inside a wave adds the run's length to cntU[u] (the reference's visiting order has ~20 triplets per user: 1 atomic in 20) and
+// the add that finds the count at zero names the user's slot for this batch: the batch position of that run head.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int IX_T = 1024;        // threads of an index workgroup
+constexpr int IX_RMAX = 8192;     // items an owner workgroup can own (LDS counters)
+constexpr int IX_LPAD = 4;        // chunk-list slots of an owner beyond one per item (hot items' extra chunks; more: overflow list)
+
+struct IndexSegArgs {
+  const int32_t *user, *pos, *neg;
+  int64_t B;
+  int U, I, R, nown, nuser;       // R items per owner workgroup, nown owner workgroups behind nuser user workgroups
+  int32_t *seg_rank, *seg_cnt, *seg_ptr;
+  // Every owner has a region of its own for its items' entries (Ce entries, twice what it expects) and for its chunk list
+  // (Lc = R + IX_LPAD slots): the usual step takes no global atomic.  An owner whose entries do not fit (hot items) reserves
+  // ALL of them behind the regions (ent_over + cursor), and chunks that do not fit go to the overflow list behind the regions.
+  int Ce, Lc, ent_over, lead_over, lead_cap;
+  int32_t *cur, *cur_next;        // this step's overflow cursor pair (entries, listed chunks) and the next step's (cleared here)
+  int4 *lead;
+  int32_t *cntU, *uslot_of;       // user side; nullptr: not wanted (the user gradients stay in the staging tables)
+  uint16_t *Wb;                   // bf16 W image (rows of untouched items are zeroed) or nullptr
+  int PS;
+  int aligned;                    // pos / neg are 16-byte aligned
+};
+
+__global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if ((int)blockIdx.x < a.nuser) {
+    // ---- user side (first in the grid: its returning atomics travel while the owners scan) ----
+    const int64_t b = (int64_t)blockIdx.x * IX_T + tid;
+    const bool valid = b < a.B;
+    const int u = valid ? clamp_quiet(a.user[b], a.U) : 0;
+    const unsigned long long vm = __ballot(valid);                  // (valid lanes are a prefix of the wave)
+    const int up = __shfl_up(u, 1, 64);
+    const bool uhead = valid && (lane == 0 || up != u);
+    const unsigned long long hm = __ballot(uhead);
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);          // lanes 0 .. lane
+    const int hl = (hm & le) ? 63 - __clzll((long long)(hm & le)) : lane;                 // first lane of my run
+    const unsigned long long stops = (hm | ~vm) & ~(hl == 63 ? ~0ull : ((2ull << hl) - 1ull));
+    const int run_end = stops ? __ffsll((long long)stops) - 1 : 64;                       // first lane after my run
+    if (valid && lane == hl) {
+      const int old = atomicAdd(a.cntU + u, run_end - hl);
+      if (old == 0) a.uslot_of[u] = (int)b;
+    }
+    return;
+  }
+  // ---- item side ----
+  extern __shared__ __attribute__((aligned(16))) int cnt[];        // [R] occurrence counters of my items
+  __shared__ int wsc[IX_T / 64], wsl[IX_T / 64];
+  __shared__ int s_gbase, s_lover, s_ltot;
+  const int w = (int)blockIdx.x - a.nuser;
+  const int lo = w * a.R;
+  const int Rw = a.I - lo < a.R ? a.I - lo : a.R;                   // > 0: nown = ceil(I / R)
+  for (int t = tid; t < Rw; t += IX_T) cnt[t] = 0;
+  if (w == 0 && tid == 0) { a.cur_next[0] = 0; a.cur_next[1] = 0; }
+  __syncthreads();
+  // My items as a SIGNED interval [Lb, Hb]: out-of-range indices are clamped like everywhere else (to item 0 / I-1; reported by
+  // k_triplet_seg), so the first owner also takes everything below 0 and the last one everything above.  Four values are
+  // rejected together: the smallest of their offsets from Lb against the interval's width -- one compare for 16 bytes; a
+  // lane with a match (1 value in `nown`) ranks it on the spot.
+  const int I = a.I;
+  const int Lb = w == 0 ? (int)0x80000000 : lo, Hb = w == a.nown - 1 ? 0x7fffffff : lo + Rw - 1;
+  const unsigned uL = (unsigned)Lb, Wm = (unsigned)Hb - (unsigned)Lb;
+  auto one = [&](int v, int64_t occ) {
+    if ((unsigned)v - uL <= Wm) a.seg_rank[occ] = atomicAdd(&cnt[clamp_quiet(v, I) - lo], 1);
+  };
+  auto four = [&](const int4 v, int64_t occ, bool in) {
+    const unsigned x0 = (unsigned)v.x - uL, x1 = (unsigned)v.y - uL, x2 = (unsigned)v.z - uL, x3 = (unsigned)v.w - uL;
+    const unsigned mn = min(min(x0, x1), min(x2, x3));
+    if (in && mn <= Wm) { one(v.x, occ); one(v.y, occ + 1); one(v.z, occ + 2); one(v.w, occ + 3); }
+  };
+#pragma unroll 1
+  for (int role = 0; role < 2; ++role) {
+    const int32_t *arr = role ? a.neg : a.pos;
+    const int64_t occ0 = role ? a.B : 0;
+    int64_t done = 0;
+    if (a.aligned) {
+      const int4 *a4 = reinterpret_cast<const int4 *>(arr);
+      const int64_t n4 = a.B >> 2;
+      // every owner reads the same bytes: each starts somewhere else (rot, in 16-KB blocks) and wraps, so that the CUs of an
+      // XCD do not all ask its L2 for the same lines at the same moment
+      const int64_t nblk = (n4 + IX_T - 1) / IX_T;                   // 16-KB blocks (the last one may be partial)
+      const int64_t rot = nblk ? (int64_t)(((unsigned)w * 2654435761u) >> 8) % nblk : 0;
+      for (int64_t blk = 0; blk < nblk; blk += 16) {                 // sixteen 16-B loads in flight per lane (256 KB per workgroup)
+        int4 v[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          int64_t bb = blk + x + rot;
+          bb = bb >= nblk ? bb - nblk : bb;
+          const int64_t e = bb * IX_T + tid;
+          v[x] = a4[e < n4 ? e : n4 - 1];                            // (unconditional: a predicated load is waited for on the spot)
+        }
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          int64_t bb = blk + x + rot;
+          bb = bb >= nblk ? bb - nblk : bb;
+          const int64_t e = bb * IX_T + tid;
+          four(v[x], occ0 + 4 * e, blk + x < nblk && e < n4);
+        }
+      }
+      done = n4 * 4;
+    }
+    for (int64_t x = done + tid; x < a.B; x += IX_T) one(arr[x], occ0 + x);
+  }
+  __syncthreads();
+  // counts are final: offsets of my items' segments and of their chunk-list entries
+  const int per = (Rw + IX_T - 1) / IX_T;
+  const int t0 = tid * per, t1 = t0 + per < Rw ? t0 + per : Rw;
+  int cs = 0, ls = 0;
+  for (int t = t0; t < t1; ++t) { const int c = cnt[t]; cs += c; ls += (c + SEG_CAP - 1) / SEG_CAP; }
+  int ic = cs, il = ls;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int vc = __shfl_up(ic, o, 64), vl = __shfl_up(il, o, 64);
+    if (lane >= o) { ic += vc; il += vl; }
+  }
+  if (lane == 63) { wsc[wv] = ic; wsl[wv] = il; }
+  __syncthreads();
+  if (tid == 0) {
+    int tc = 0, tl = 0;
+    for (int q = 0; q < IX_T / 64; ++q) { const int vc = wsc[q], vl = wsl[q]; wsc[q] = tc; wsl[q] = tl; tc += vc; tl += vl; }
+    s_gbase = tc <= a.Ce ? w * a.Ce : a.ent_over + atomicAdd(a.cur, tc);
+    s_lover = tl > a.Lc ? a.lead_over + atomicAdd(a.cur + 1, tl - a.Lc) : 0;
+    s_ltot = tl;
+  }
+  __syncthreads();
+  int e = s_gbase + wsc[wv] + ic - cs, l = wsl[wv] + il - ls;      // l: position in my chunk list
+  int4 *const myl = a.lead + (size_t)w * a.Lc;
+  for (int t = t0; t < t1; ++t) {
+    const int c = cnt[t], item = lo + t;
+    a.seg_cnt[item] = c;
+    a.seg_ptr[item] = e;
+    for (int q = 0; q * SEG_CAP < c; ++q, ++l) {
+      const int4 ent = make_int4(item, e + q * SEG_CAP, c - q * SEG_CAP < SEG_CAP ? c - q * SEG_CAP : SEG_CAP, c);
+      if (l < a.Lc) myl[l] = ent;
+      else if (s_lover + (l - a.Lc) < a.lead_cap) a.lead[s_lover + (l - a.Lc)] = ent;
+    }
+    e += c;
+    if (c == 0 && a.Wb) {
+      uint4 *row = reinterpret_cast<uint4 *>(a.Wb + (size_t)item * a.PS);       // PS % 16 == 0: whole 16-B pieces
+      for (int x = 0; x < a.PS / 8; ++x) row[x] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  for (int x = s_ltot + tid; x < a.Lc; x += IX_T) myl[x] = make_int4(0, 0, 0, 0);      // unused slots: no work
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Segment-mode triplet kernel (round 3).  One lane group per triplet: forward scores, g, the two segment entries -- as
+// before -- and the USER side without a staging round trip: the per-occurrence user-row gradients of the workgroup's
+// TS_T / G consecutive triplets go to LDS, the runs of equal users inside the workgroup are summed there IN ORDER (one wave
+// per run, lane = column), and
+//   mode 0 (sgd): a run that holds ALL the batch's occurrences of its user (cntU[u], k_index_seg) finishes the user right
+//          here -- the pre-update row goes to uold[slot] for k_item_seg, the table row is updated in place; a user whose
+//          occurrences span workgroups (a run cut by a workgroup boundary, a user with several runs) meets in the staging
+//          row: atomic adds, then the occurrence counter udone[slot]; the workgroup that completes the count reads the
+//          total back where the atomics live and finishes the user.  No apply pass, no claim marks.
+//   mode 1 (adam_tf23, exported user gradients): the run sums are added to the staging rows and the user is marked.
+// In the reference's visiting order (runs of ~20 triplets) that is 2 atomic row adds per workgroup of 32 triplets instead of
+// one per wave or per triplet, and every sum inside a run is taken in batch order.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TS_T = 512;
+
+struct SegUser {
+  int mode;
+  const int32_t *uslot_of;
+  int32_t *udone;
+  float *uold;
+};
+
+template <int G>
+__global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, const int32_t *__restrict__ user,
+                                                      const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
+  constexpr int T = TS_T / G;                               // triplets per workgroup (<= 64)
+  __shared__ __attribute__((aligned(16))) float rows[4096];  // [T][k + d], k + d <= 8 G
+  __shared__ int s_user[T], s_slot[T], s_tot[T];
+  const int tl = threadIdx.x / G, lane = threadIdx.x % G;
+  const int64_t b0 = (int64_t)blockIdx.x * T + tl;
+  const bool valid = b0 < B;                                // (the surplus groups of the last workgroup run along: barriers)
+  const int64_t b = valid ? b0 : B - 1;
+  const int u_raw = user[b], i_raw = pos[b], j_raw = neg[b];
+  const int u = clamp_idx(u_raw, a.U, a.errflag, 1);
+  const int i = clamp_idx(i_raw, a.I, a.errflag, 2), j = clamp_idx(j_raw, a.I, a.errflag, 3);
+  const int k = a.k, d = a.d, kd = k + d;
+  // everything that depends on the indices alone is requested together with the rows
+  const float bi = a.Bi[i], bj = a.Bi[j];
+  int spI = a.seg_rank[b] + a.seg_ptr[i], spJ = a.seg_rank[B + b] + a.seg_ptr[j];
+  {
+    const unsigned top = (unsigned)a.seg_cap - 1u;          // (never beyond the allocation, whatever the index state holds)
+    spI = (int)((unsigned)spI < top ? (unsigned)spI : top); spJ = (int)((unsigned)spJ < top ? (unsigned)spJ : top);
+  }
+  int slot = 0, tot = 0;
+  if (su.mode == 0) { slot = su.uslot_of[u]; tot = a.cntU[u]; }
+  const int c4 = lane * 4;
+  const bool hk = c4 < k, hd = c4 < d;
+  const int ck = hk ? c4 : 0, cd = hd ? c4 : 0;
+  const float mk = hk ? 1.f : 0.f, md = hd ? 1.f : 0.f;
+  const float *gu = a.Gu + (size_t)u * k, *gi = a.Gi + (size_t)i * k, *gj = a.Gi + (size_t)j * k;
+  const float4 p = ld4(gu + ck), q = ld4(gi + ck), r = ld4(gj + ck);
+  float4 tp = make_float4(0.f, 0.f, 0.f, 0.f), tq = tp, tr = tp;
+  float pid = 0.f, pjd = 0.f;
+  if (d) {
+    const float *tu = a.Tu + (size_t)u * d, *Pi = a.P + (size_t)i * a.PS, *Pj = a.P + (size_t)j * a.PS;
+    tp = ld4(tu + cd); tq = ld4(Pi + cd); tr = ld4(Pj + cd);
+    pid = Pi[d]; pjd = Pj[d];
+  }
+  // ---- forward: the un-differenced per-item scores of the reference (BPRMF.py:101-102) ----
+  float si = mk * (p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w);
+  float sj = mk * (p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w);
+  float nrm = mk * (p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w + q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w +
+                    r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  float ti = 0.f, tj = 0.f;
+  if (d) {
+    ti = md * (tp.x * tq.x + tp.y * tq.y + tp.z * tq.z + tp.w * tq.w);
+    tj = md * (tp.x * tr.x + tp.y * tr.y + tp.z * tr.z + tp.w * tr.w);
+    nrm += md * (tp.x * tp.x + tp.y * tp.y + tp.z * tp.z + tp.w * tp.w);
+  }
+  si = group_sum<G>(si); sj = group_sum<G>(sj); nrm = group_sum<G>(nrm);
+  float xp = bi + si, xn = bj + sj;
+  if (d) {
+    ti = group_sum<G>(ti); tj = group_sum<G>(tj);
+    xp = xp + ti + pid;
+    xn = xn + tj + pjd;
+  }
+  const float diff = xp - xn;
+  const bool inr = (diff >= -80.0f) && (diff <= 1e8f);                 // tf.clip_by_value gradient mask
+  const float cl = fminf(fmaxf(diff, -80.0f), 1e8f);
+  const float z = -cl;                                                 // softplus(z), stable form
+  const float sp = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
+  const float g = inr ? -1.0f / (1.0f + expf(diff)) : 0.f;            // -sigmoid(-diff)
+  const float reg = a.reg, r2 = 2.f * reg, lr = a.lr;
+  if (lane == 0 && valid) {
+    a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
+    const int key = su.mode == 0 ? slot : u;                           // where k_item_seg finds the pre-update user row
+    a.seg_ent[spI] = make_int2(key, __float_as_int(g));
+    a.seg_ent[spJ] = make_int2((int)((unsigned)key | 0x80000000u), __float_as_int(g));
+  }
+  // ---- user side: per-occurrence gradient rows -> LDS, runs summed in order ----
+  float *row = rows + tl * kd;
+  if (hk) *reinterpret_cast<float4 *>(row + c4) = make_float4(g * (q.x - r.x) + r2 * p.x, g * (q.y - r.y) + r2 * p.y,
+                                                              g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w);
+  if (hd) *reinterpret_cast<float4 *>(row + k + c4) = make_float4(g * (tq.x - tr.x) + r2 * tp.x, g * (tq.y - tr.y) + r2 * tp.y,
+                                                                  g * (tq.z - tr.z) + r2 * tp.z, g * (tq.w - tr.w) + r2 * tp.w);
+  if (lane == 0) { s_user[tl] = valid ? u : -1 - tl; s_slot[tl] = slot; s_tot[tl] = tot; }
+  __syncthreads();
+  const int wl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int myu = wl < T ? s_user[wl] : 0, pru = (wl > 0 && wl < T) ? s_user[wl - 1] : 0;
+  const unsigned long long hm = __ballot(wl < T && (wl == 0 || myu != pru));     // run heads among the workgroup's triplets
+  const int nseg = __popcll(hm);
+  for (int sg = wv; sg < nseg; sg += TS_T / 64) {                                // wave-uniform
+    unsigned long long m = hm;
+    for (int x = 0; x < sg; ++x) m &= m - 1;
+    const int s0 = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int s1 = m ? __ffsll((long long)m) - 1 : T;
+    const int uu = s_user[s0];
+    if (uu < 0) continue;
+    const int seglen = s1 - s0;
+    float acc[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int c = wl + 64 * x;
+      float sum = 0.f;
+      if (c < kd)
+        for (int t = s0; t < s1; ++t) sum += rows[t * kd + c];
+      acc[x] = sum;
+    }
+    float *const tG = a.wGu + (size_t)uu * k, *const tT = d ? a.wTu + (size_t)uu * d : nullptr;
+    float *const sG = a.dGu + (size_t)uu * k, *const sT = d ? a.dTu + (size_t)uu * d : nullptr;
+    if (su.mode != 0) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) atomicAdd(c < k ? sG + c : sT + (c - k), acc[x]); }
+      if (wl == 0) a.flagU[uu] = 1u;
+      continue;
+    }
+    const int sl = s_slot[s0], total = s_tot[s0];
+    float *const uo = su.uold + (size_t)sl * kd;
+    if (seglen == total) {                                  // the whole user is here: finish it (no atomics)
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int c = wl + 64 * x;
+        if (c < kd) { float *t = c < k ? tG + c : tT + (c - k); const float old = *t; uo[c] = old; *t = old - lr * acc[x]; }
+      }
+      if (wl == 0) a.cntU[uu] = 0;
+      continue;
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) atomicAdd(c < k ? sG + c : sT + (c - k), acc[x]); }
+    // the adds execute at the memory side; the counter may move only once they have been performed (their acknowledgements)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int dn = 0;
+    if (wl == 0) dn = atomicAdd(su.udone + sl, seglen);
+    dn = __shfl(dn, 0, 64);
+    if (dn + seglen != total) continue;                     // somebody else completes this user
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int c = wl + 64 * x;
+      if (c < kd) {
+        float *st = c < k ? sG + c : sT + (c - k), *t = c < k ? tG + c : tT + (c - k);
+        const float tsum = atomicAdd(st, 0.f);              // the total, read where the atomics live
+        *st = 0.f;                                          // staging back to all-zero
+        const float old = *t; uo[c] = old; *t = old - lr * tsum;
+      }
+    }
+    if (wl == 0) { su.udone[sl] = 0; a.cntU[uu] = 0; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Item-side gradients without global float atomics ("occurrence segments").
 //   k_row_count    the returning count atomic gives every occurrence its rank within its item
 //   k_seg_alloc    the rank-0 occurrence reserves a contiguous segment of cnt[item] entries (wave-aggregated bump)
@@ -1175,26 +1363,22 @@ struct AdamFuse { float *mGi, *vGi, *mBi, *vBi; int32_t *lastI; float b1, b2, ep
 
 template <int G, int ADAM>
 __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
-                                                  float *__restrict__ Wf, uint16_t *__restrict__ Wb,
-                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B,
-                                                  float lr, AdamFuse af) {
+                                                  float *__restrict__ Wf, uint16_t *__restrict__ Wb, float lr, AdamFuse af) {
   const int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
-  // one lane group per chunk leader (k_seg_alloc's list): rank 0 owns an ordinary item, ranks 0, CAP, 2 CAP, ... share a
-  // hot one.  (BPRX_SEG_LEAD=0: one group per occurrence, the non-leaders leave)
-  int64_t job = e0;
-  if (a.seg_nlead) {
-    if (e0 >= a.seg_nlead[0]) return;
-    job = a.seg_lead[e0];
-  } else if (job >= 2 * B) return;
-  const int rk = a.seg_rank[job];
-  const int item_raw = job < B ? pos[job] : neg[job - B];            // (requested together with the rank, not after it)
-  if (rk % SEG_CAP != 0) return;
-  const int item = clamp_quiet(item_raw, a.I);
-  const int n = a.cntI[item];
-  const int e_first = a.seg_ptr[item] + rk;
-  int ns = n - rk < SEG_CAP ? n - rk : SEG_CAP;
-  if (a.seg_guard && (e_first < 0 || e_first + ns > a.seg_cap)) ns = 0;   // (index state of another batch: see seg_cap)
+  // one lane group per listed chunk (k_index_seg): an ordinary item is one chunk, a hot one is cut into chunks of SEG_CAP
+  // (the owners' regions first -- unused slots hold no work -- then the overflow list, whose length is read on the device)
+  if (e0 >= a.seg_lead_over) {
+    int nl = a.seg_nlead[0];
+    nl = nl < a.seg_lead_cap - a.seg_lead_over ? nl : a.seg_lead_cap - a.seg_lead_over;
+    if (e0 - a.seg_lead_over >= nl) return;
+  }
+  const int4 job = a.seg_lead[e0];
+  if (job.z <= 0) return;
+  const int item = clamp_quiet(job.x, a.I);
+  const int n = job.w;
+  int e_first = job.y, ns = job.z;
+  if (e_first < 0 || ns < 0 || e_first + ns > a.seg_cap) ns = 0;    // (never beyond the allocation)
   const int2 *ent = a.seg_ent + e_first;
   const int k = a.k, d = a.d;
   const int c4 = lane * 4;
@@ -1208,8 +1392,8 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   // rows -- three dependent round trips per iteration instead of two.
   const int ck = hk ? c4 : 0, cd = hd ? c4 : 0;
   const float mk = hk ? 1.f : 0.f, md = hd ? 1.f : 0.f;
-  const float *TuS = d ? a.Tu : a.Gu;                                 // d == 0: any valid address, md == 0
-  const int ds = d ? d : k;
+  const float *const UG = a.uG, *const UT = d ? a.uT : a.uG;          // d == 0: any valid address, md == 0
+  const int gs = a.usG, ds = d ? a.usT : a.usG;
   // the item's own row and bias depend on `item` alone: requested now, beside the first entries, not after the loop
   const size_t og = (size_t)item * k + c4, ow = (size_t)item * a.PS;
   float4 q = ld4(Gi + (size_t)item * k + ck);
@@ -1217,8 +1401,8 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   for (; e + 2 <= ns; e += 2) {                                       // two entries in flight
     const int2 r0 = ent[e], r1 = ent[e + 1];
     const int u0 = r0.x & 0x7fffffff, u1 = r1.x & 0x7fffffff;
-    const float4 p0 = ld4(a.Gu + (size_t)u0 * k + ck), p1 = ld4(a.Gu + (size_t)u1 * k + ck);
-    const float4 t0 = ld4(TuS + (size_t)u0 * ds + cd), t1 = ld4(TuS + (size_t)u1 * ds + cd);
+    const float4 p0 = ld4(UG + (size_t)u0 * gs + ck), p1 = ld4(UG + (size_t)u1 * gs + ck);
+    const float4 t0 = ld4(UT + (size_t)u0 * ds + cd), t1 = ld4(UT + (size_t)u1 * ds + cd);
     const float s0 = r0.x < 0 ? -__int_as_float(r0.y) : __int_as_float(r0.y);
     const float s1 = r1.x < 0 ? -__int_as_float(r1.y) : __int_as_float(r1.y);
     nj += (r0.x < 0) + (r1.x < 0);
@@ -1230,8 +1414,8 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
   if (e < ns) {
     const int2 r0 = ent[e];
     const int u0 = r0.x & 0x7fffffff;
-    const float4 p0 = ld4(a.Gu + (size_t)u0 * k + ck);
-    const float4 t0 = ld4(TuS + (size_t)u0 * ds + cd);
+    const float4 p0 = ld4(UG + (size_t)u0 * gs + ck);
+    const float4 t0 = ld4(UT + (size_t)u0 * ds + cd);
     const float s0 = r0.x < 0 ? -__int_as_float(r0.y) : __int_as_float(r0.y);
     nj += (r0.x < 0);
     gsum += s0;
@@ -1348,7 +1532,11 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
       if (lane == 0) Wf[ow + d] = wl;
     }
   }
-  if (lane == 0) a.cntI[item] = 0;                                    // reset for the next step
+}
+
+// segment-mode step whose users are finished inside k_triplet_seg (sgd, gradients not exported): no apply pass for them
+inline bool seg_finishes_users(const bprx_handle *h) {
+  return h->item_mode && h->cfg.optimizer == BPRX_OPT_SGD && !(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD);
 }
 
 SparseArgs make_args(bprx_handle *h, const float *P) {
@@ -1365,17 +1553,20 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   a.fastU = h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD);
   a.fastI = h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD);
   a.lr = h->cfg.lr;
-  a.item_atomics = h->item_mode ? 0 : 1;
   if (h->item_mode) {
     // every item row is finished by k_item_seg, which gathers PRE-update user rows after k_triplet_grad: the user
     // side may therefore not be updated in place either (staging + k_apply_sgd)
     a.fastI = 0; a.fastU = 0; a.fast = 0;
   }
   a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
-  static const int seg_lead_env = getenv("BPRX_SEG_LEAD") ? atoi(getenv("BPRX_SEG_LEAD")) : 1;
-  a.seg_lead = h->seg_lead; a.seg_nlead = (h->seg_cursor && seg_lead_env) ? h->seg_cursor + 1 : nullptr;
-  a.seg_cap = (int)(2 * h->cfg.max_batch);
-  a.seg_guard = h->idx_hinted ? 1 : 0;
+  a.seg_lead = (const int4 *)h->seg_lead; a.seg_lead_cap = (int)h->seg_lead_cap;
+  a.seg_nlead = h->seg_cursor ? h->seg_cursor + 2 * h->seg_cur_slot + 1 : nullptr;
+  a.seg_lead_over = h->seg_lead_over;
+  a.seg_cap = (int)h->seg_ent_cap;
+  // where k_item_seg finds the pre-update user rows: a segment-mode sgd step finishes its users inside k_triplet_seg and
+  // keeps their old rows in uold (entry key = user slot); otherwise the tables are untouched until the apply pass
+  if (seg_finishes_users(h)) { a.uG = h->uold; a.uT = h->uold + a.k; a.usG = a.usT = a.k + a.d; }
+  else { a.uG = h->t.Gu; a.uT = h->t.Tu; a.usG = a.k; a.usT = a.d; }
   // shared-row list: both sides on the exclusive-row fast path (sgd, atomic staging, no exported gradients)
   a.use_list = (h->slist && a.fastU && a.fastI) ? 1 : 0;
   static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
@@ -1768,24 +1959,47 @@ int bprx_launch_score(bprx_handle *h, const int32_t *u, const int32_t *i, int64_
 // projection (bprx_step_begin)
 int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, hipStream_t s) {
   SparseArgs a = make_args(h, h->P);
-  if (h->fast_rows || h->item_mode || h->list_mode) {
+  if (h->item_mode) {
+    // segment mode: ranks, counts, segment offsets, the chunk list of k_item_seg, the users' counts and slots -- one launch
     BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
-    const bool zw = h->item_mode && a.d && h->cfg.feat_dtype != BPRX_F_FP32 && !h->pf_launching;   // bf16 W image: rows of untouched items
-    // (a prefetched pass runs while the previous step still writes / reads that image: its dense update zeroes it instead)
+    IndexSegArgs x;
+    x.user = u; x.pos = i; x.neg = j; x.B = B; x.U = a.U; x.I = a.I;
+    int nown = h->num_cu > 0 ? h->num_cu : 256;                                  // one owner workgroup per CU ...
+    if (nown > 1024) nown = 1024;
+    if ((a.I + nown - 1) / nown > IX_RMAX) nown = (a.I + IX_RMAX - 1) / IX_RMAX;   // ... more when a range would not fit LDS
+    if (nown > a.I) nown = a.I;
+    x.R = (a.I + nown - 1) / nown;
+    x.nown = (a.I + x.R - 1) / x.R;
+    x.seg_rank = h->seg_rank; x.seg_cnt = h->seg_cnt; x.seg_ptr = h->seg_ptr;
+    x.Ce = (int)(2 * ((2 * B + x.nown - 1) / x.nown) + 64);
+    x.Lc = x.R + IX_LPAD;
+    x.ent_over = x.nown * x.Ce; x.lead_over = x.nown * x.Lc; x.lead_cap = (int)h->seg_lead_cap;
+    if ((int64_t)x.ent_over + 2 * B > h->seg_ent_cap || (int64_t)x.lead_over + 2 * B / SEG_CAP + 64 > h->seg_lead_cap)
+      BPRX_FAIL(h, BPRX_E_STATE, "index pass: segment buffers too small (I=%d, B=%lld)", a.I, (long long)B);
+    h->seg_lead_over = x.lead_over;
+    h->seg_cur_slot = h->seg_slot;                                               // the pair this step's kernels read
+    x.cur = h->seg_cursor + 2 * h->seg_slot; x.cur_next = h->seg_cursor + 2 * (h->seg_slot ^ 1);
+    h->seg_slot ^= 1;
+    x.lead = (int4 *)h->seg_lead;
+    const bool users = seg_finishes_users(h);
+    x.cntU = users ? h->cntU : nullptr; x.uslot_of = users ? h->uslot_of : nullptr;
+    const bool zw = a.d && h->cfg.feat_dtype != BPRX_F_FP32;                      // bf16 W image: rows of untouched items
+    x.Wb = zw ? (uint16_t *)h->Wb : nullptr; x.PS = a.PS;
+    x.aligned = (((uintptr_t)i | (uintptr_t)j) & 15) == 0;
+    x.nuser = users ? (int)((B + IX_T - 1) / IX_T) : 0;
+    hipLaunchKernelGGL(k_index_seg, dim3((unsigned)(x.nown + x.nuser)), dim3(IX_T), (size_t)x.R * sizeof(int), s, x);
+    BPRX_LAUNCH_CHECK(h, "k_index_seg");
+    return BPRX_OK;
+  }
+  if (h->fast_rows || h->list_mode) {
+    BprxProfScope pc(h, BPRX_PHASE_ROW_COUNT, s);
     const int64_t cap = 2 * B < (int64_t)a.I ? 2 * B : (int64_t)a.I;
     hipLaunchKernelGGL(k_row_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, u, i, j, B, a.U, a.I, h->cntU, h->cntI,
-                       a.fastU, (a.fastI || h->list_mode) ? 1 : 0, h->item_mode ? h->seg_rank : (int32_t *)nullptr,
-                       h->item_mode ? h->seg_cursor : (int32_t *)nullptr, (uint4 *)(zw ? h->Wb : nullptr),
-                       zw ? (size_t)a.I * a.PS * sizeof(uint16_t) / 16 : (size_t)0,
+                       a.fastU, (a.fastI || h->list_mode) ? 1 : 0,
                        h->list_mode ? h->ilist : (int32_t *)nullptr, h->list_cur, (int)cap,
                        a.use_list ? a.slist : (int32_t *)nullptr, a.slist_n, (int)(3 * h->cfg.max_batch));
   }
-  if (h->item_mode) {
-    BprxProfScope pc(h, BPRX_PHASE_SEG_ALLOC, s);
-    hipLaunchKernelGGL(k_seg_alloc, dim3((unsigned)((2 * B + 1023) / 1024)), dim3(1024), 0, s, i, j, B, a.I, h->seg_rank, h->cntI,
-                       h->seg_ptr, h->seg_cursor, h->seg_lead);
-  }
-  BPRX_LAUNCH_CHECK(h, "k_row_count/k_seg_alloc");
+  BPRX_LAUNCH_CHECK(h, "k_row_count");
   return BPRX_OK;
 }
 
@@ -1803,8 +2017,17 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   if (leaves_dirty || (a.d && h->W_dirty))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   h->W_dirty = leaves_dirty;
-  if (h->item_mode) DISPATCH_G(G, vec, k_triplet_grad_seg, grid_for(B, G), s, a, u, i, j, B);
-  else DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
+  if (h->item_mode) {                                   // (segment mode implies the 16-B-per-lane layout: k % 4 == d % 4 == 0)
+    const SegUser su = {seg_finishes_users(h) ? 0 : 1, h->uslot_of, h->udone, h->uold};
+    const int Gs = pick_group(a.k, a.d, true);
+    const dim3 grid((unsigned)((B * Gs + TS_T - 1) / TS_T));
+    switch (Gs) {
+      case 8: hipLaunchKernelGGL((k_triplet_seg<8>), grid, dim3(TS_T), 0, s, a, su, u, i, j, B); break;
+      case 16: hipLaunchKernelGGL((k_triplet_seg<16>), grid, dim3(TS_T), 0, s, a, su, u, i, j, B); break;
+      case 32: hipLaunchKernelGGL((k_triplet_seg<32>), grid, dim3(TS_T), 0, s, a, su, u, i, j, B); break;
+      default: hipLaunchKernelGGL((k_triplet_seg<64>), grid, dim3(TS_T), 0, s, a, su, u, i, j, B); break;
+    }
+  } else DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
   return BPRX_OK;
 }
@@ -1819,13 +2042,15 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
   uint16_t *Wb = a.d && bf ? (uint16_t *)h->Wb : nullptr;
   const AdamFuse af = {h->t.m_Gi, h->t.v_Gi, h->t.m_Bi, h->t.v_Bi, h->lastI, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, (int)h->adam_t};
   BprxProfScope ps(h, BPRX_PHASE_ITEM_SEG, s);
-  // (the bf16 image was re-zeroed by k_row_count: rows of untouched items stay zero)
-  const dim3 grid = grid_for(2 * B, G);
+  // (k_index_seg zeroed the bf16 rows of this batch's untouched items)
+  // one lane group per chunk-list slot: the owners' regions (~one slot per item) + the overflow list (hot items' extra chunks)
+  const int64_t bound = (int64_t)h->seg_lead_over + 2 * B / SEG_CAP + 64;
+  const dim3 grid = grid_for(bound, G);
 #define LAUNCH_SEG(GG)                                                                                                   \
   do {                                                                                                                   \
-    if (adam == 2) hipLaunchKernelGGL((k_item_seg<GG, 2>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t, af); \
-    else if (adam) hipLaunchKernelGGL((k_item_seg<GG, 1>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t, af); \
-    else hipLaunchKernelGGL((k_item_seg<GG, 0>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, i, j, B, lr_t, af);          \
+    if (adam == 2) hipLaunchKernelGGL((k_item_seg<GG, 2>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
+    else if (adam) hipLaunchKernelGGL((k_item_seg<GG, 1>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
+    else hipLaunchKernelGGL((k_item_seg<GG, 0>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af);          \
   } while (0)
   switch (G) {
     case 8: LAUNCH_SEG(8); break;
@@ -1841,6 +2066,7 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
 int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, float lr_t, hipStream_t s) {
   SparseArgs a = make_args(h, nullptr);
   const size_t U = a.U, I = a.I, k = a.k, d = a.d;
+  if (seg_finishes_users(h)) return BPRX_OK;             // k_item_seg finished the items, k_triplet_seg the users
   BprxProfScope ps(h, BPRX_PHASE_APPLY, s);
   if (h->cfg.optimizer == BPRX_OPT_SGD) {
     const bool vec = vec_ok(h);
@@ -1856,7 +2082,8 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
       BPRX_LAUNCH_CHECK(h, "k_apply_sgd_list");
       return BPRX_OK;
     }
-    const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;
+    // (segment mode: k_item_seg finished the items and k_triplet_seg the users: nothing is left to apply)
+    const int fk = ((h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) || h->item_mode) ? 1 : 0;
     const int ek = (h->item_mode || (h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 3;
     if (ek > fk)
       DISPATCH_G(G, vec, k_apply_sgd, grid_for((int64_t)(ek - fk) * B, G), s, h->t.Gu, h->t.Gi, h->t.Bi, h->t.Tu, a, u, i, j, B,
@@ -1959,10 +2186,7 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
                      lm ? h->ilist_n + (h->list_slot ^ 1) : (int32_t *)nullptr, (int)bound, h->W,
                      (lm && h->list_reset_cnt) ? h->cntI : (int32_t *)nullptr,
                      // fp8: the slot the next k_cast_Et8 reads (cleared by the last one)
-                     h->cfg.feat_dtype == BPRX_F_FP8 ? (uint32_t *)h->qs + 2 + h->qs_slot : (uint32_t *)nullptr,
-                     (uint4 *)(h->pf_zero_w ? h->Wb : nullptr),
-                     h->pf_zero_w ? (size_t)h->cfg.num_items * h->PS * sizeof(uint16_t) / 16 : (size_t)0);
-  h->pf_zero_w = false;
+                     h->cfg.feat_dtype == BPRX_F_FP8 ? (uint32_t *)h->qs + 2 + h->qs_slot : (uint32_t *)nullptr);
   BPRX_LAUNCH_CHECK(h, "k_dense_update");
   h->absmax_valid = h->cfg.feat_dtype == BPRX_F_FP8;
   if (lm) { h->list_slot ^= 1; h->list_mode = 0; }      // the step's list is consumed

@@ -168,11 +168,6 @@ class Engine:
     def step_begin(self, user, pos, neg):
         _ffi.check(self.h, self.lib.bprx_step_begin(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), _stream()))
 
-    def hint_next_batch(self, user, pos, neg):
-        """bprx_hint_next_batch: the index tensors of the step AFTER the coming one (kept alive here until they are used)."""
-        self._hint_idx = (user, pos, neg)
-        _ffi.check(self.h, self.lib.bprx_hint_next_batch(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel()))
-
     def step_begin_sparse(self, user, pos, neg):
         """First half of step_begin (the user-side gradients are final afterwards); the index tensors must stay alive and
         unchanged until step_begin_dense has been called."""

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BPRX_ABI_VERSION 5
+#define BPRX_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define BPRX_API __attribute__((visibility("default")))
@@ -162,15 +162,6 @@ BPRX_API int bprx_step_end(bprx_handle *h, float *loss_out, void *stream);
 BPRX_API int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B,
                            void *stream);
 BPRX_API int bprx_step_begin_dense(bprx_handle *h, void *stream);
-/* Optional pipelining hint (host-only call): user/pos/neg/B are the index buffers of the step AFTER the coming one --
-   already filled, or filled by work enqueued on the coming step's stream before that step.  The coming step then runs that
-   batch's index pass (row multiplicities, occurrence ranks, segment offsets: two latency-bound kernels that depend on the
-   indices only) on a side stream beside its own per-triplet kernels, and the step after it, called with exactly these
-   pointers and B, skips the pass.  The buffers must not change between the coming step and the end of the step that uses
-   them (i.e. alternate two sets of buffers).  Results are those of the unhinted sequence; a hint that is not followed is
-   discarded. */
-BPRX_API int bprx_hint_next_batch(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B);
-
 /* Item-sharded multi-GPU helpers.
    bprx_step_project: the item-projection prologue of the step (P = F.[E|Bp]) on its own, so that it can overlap the
    all-to-all that fetches the user rows; a following bprx_step_begin does not repeat it.

@@ -172,8 +172,6 @@ def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather
         mine = [tuple(dev(x) for x in bs[rank]) for bs in all_batches]
         for step in range(nsteps):
             batches = all_batches[step]
-            if step + 1 < nsteps:                         # the next step's index pass beside this step (bprx_hint_next_batch)
-                m.eng.hint_next_batch(*mine[step + 1])
             m.step(*mine[step])
             o.step(np.concatenate([b[0] for b in batches]), np.concatenate([b[1] + r * ish for r, b in enumerate(batches)]),
                    np.concatenate([b[2] + r * ish for r, b in enumerate(batches)]), opt, lr, reg)
@@ -356,7 +354,6 @@ def _worker_nosync(rank, world, port):
             torch.cuda.synchronize()
             torch.cuda.set_sync_debug_mode("error")
             try:
-                m.eng.hint_next_batch(*bt[3])
                 m.step(*bt[2]); m.step(*bt[3])
             finally:
                 torch.cuda.set_sync_debug_mode("default")

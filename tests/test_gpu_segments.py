@@ -1,0 +1,90 @@
+"""Segment-mode step (k_index_seg / k_triplet_seg / k_item_seg, round 3) against the CPU oracle on batch shapes that
+exercise each of its paths: users finished inside one workgroup, users whose run is cut by a workgroup boundary, users
+with several separate runs (the occurrence counter + last-arriver hand-off), singletons, the reference's user-grouped
+order and an i.i.d. order; hot items whose entries overflow their owner's entry region and chunk list; indices at both
+ends of the item range; several steps on one handle (every counter must be back at zero between steps)."""
+import numpy as np
+import pytest
+import torch
+
+from fashionvisualexpl_recommend_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(U, I, k, d, D, seed):
+    rs = np.random.RandomState(seed)
+    t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k),
+             Bi=(rs.standard_normal(I) * 0.01).astype(np.float32))
+    if d:
+        F = synth.make_features(I, D, seed=seed)
+        F = orc.bf16_round((F / np.abs(F).max()).astype(np.float32))
+        t.update(Tu=synth.glorot_uniform(rs, U, d), F=F, E=synth.glorot_uniform(rs, D, d),
+                 Bp=synth.glorot_uniform(rs, D, 1).reshape(-1))
+    return t
+
+
+def _grouped_users(rs, U, B, kinds):
+    """A user column made of runs: `kinds` cycles through run lengths (1 = singleton, 37 > a 32-triplet workgroup ...);
+    every fifth run re-uses an EARLIER user, so that user has several separate runs in the batch."""
+    out, seen, n = [], [], 0
+    while len(out) < B:
+        ln = kinds[n % len(kinds)]
+        u = seen[rs.randint(len(seen))] if (n % 5 == 4 and seen) else int(rs.randint(U))
+        seen.append(u)
+        out += [u] * ln
+        n += 1
+    return np.asarray(out[:B], np.int32)
+
+
+@pytest.mark.parametrize("model,k,d", [("bprmf", 32, 0), ("vbpr", 64, 64), ("vbpr", 128, 20), ("bprmf", 256, 0), ("vbpr", 8, 4)])
+@pytest.mark.parametrize("order", ["grouped", "iid"])
+def test_segment_step_user_runs_and_hot_items(model, k, d, order, monkeypatch):
+    monkeypatch.setenv("BPRX_ITEM_MODE", "2")              # segments whatever 2B : I is
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    U, I, B, D = 500, 300, 1000, 128
+    t = _tables(U, I, k, d, D if d else 0, seed=k + d)
+    kw = dict(embed_d=d, feat_dim=D, feat_dtype="bf16") if d else {}
+    lr, reg = 0.05, 1e-3
+    e = Engine(model=model, num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=lr, reg=reg, max_batch=B, **kw).bind(**t)
+    o = orc.OracleModel(**t, quant=1 if d else 0)
+    rs = np.random.RandomState(5)
+    for step in range(4):
+        nb = B if step != 2 else B - 77                     # a ragged batch in between
+        if order == "grouped":
+            u = _grouped_users(rs, U, nb, [20, 37, 1, 64, 3, 19, 130])
+        else:
+            u = rs.randint(U, size=nb).astype(np.int32)
+        i, j = rs.randint(I, size=nb).astype(np.int32), rs.randint(I, size=nb).astype(np.int32)
+        i[:300] = 11                                        # 300 + 150 occurrences of one item: beyond its owner's entry
+        j[300:450] = 11                                     # region (overflow cursor) and chunk list (overflow list)
+        i[500:600] = 0                                      # both ends of the item range
+        j[600:700] = I - 1
+        loss = e.step(torch.as_tensor(u, device="cuda"), torch.as_tensor(i, device="cuda"), torch.as_tensor(j, device="cuda")).item()
+        want = o.step(u, i, j, "sgd", lr, reg)
+        assert loss == pytest.approx(want, rel=1e-4 if d else 2e-5)
+        rt, at = (2e-5, 2e-6) if not d else (2e-3, 1e-4)
+        for n in (("Gu", "Gi", "Bi", "Tu", "E", "Bp") if d else ("Gu", "Gi", "Bi")):
+            np.testing.assert_allclose(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rtol=rt, atol=at,
+                                       err_msg="%s step %d" % (n, step))
+    e.sync_check()
+
+
+def test_segment_step_reports_out_of_range_indices_without_faulting(monkeypatch):
+    monkeypatch.setenv("BPRX_ITEM_MODE", "2")
+    from fashionvisualexpl_recommend_amd import _ffi
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    U, I, k, B = 50, 40, 32, 256
+    t = _tables(U, I, k, 0, 0, seed=3)
+    e = Engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=0.05, reg=0.0, max_batch=B).bind(**t)
+    rs = np.random.RandomState(1)
+    u, i, j = (rs.randint(n, size=B).astype(np.int32) for n in (U, I, I))
+    i[3], j[9], u[17] = -5, I + 1000, U + 3
+    e.step(*(torch.as_tensor(a, device="cuda") for a in (u, i, j)))
+    with pytest.raises(_ffi.BprxError):
+        e.sync_check()
+    u, i, j = (rs.randint(n, size=B).astype(np.int32) for n in (U, I, I))      # the handle is usable afterwards
+    e.step(*(torch.as_tensor(a, device="cuda") for a in (u, i, j)))
+    e.sync_check()
+    assert all(np.isfinite(e.t[n].cpu().numpy()).all() for n in ("Gu", "Gi", "Bi"))

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(tier):
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _ffi.lib().bprx_abi_version() == _ffi.ABI_VERSION == 5
+    assert _ffi.lib().bprx_abi_version() == _ffi.ABI_VERSION == 6
 
 
 def test_create_rejects_bad_config_without_gpu_work():
