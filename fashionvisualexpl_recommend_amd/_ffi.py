@@ -68,9 +68,9 @@ def lib():
         "bprx_last_error": (C.c_char_p, [vp]),
         "bprx_bind_tables": (C.c_int, [vp, C.POINTER(Tables)]),
         "bprx_set_hyper": (C.c_int, [vp, f32, f32]),
-        "bprx_tables_dirty": (C.c_int, [vp]),
+        "bprx_tables_dirty": (C.c_int, [vp, vp]),
         "bprx_kernel_variant_safe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-        "bprx_set_adam_step": (C.c_int, [vp, i64]),
+        "bprx_set_adam_step": (C.c_int, [vp, i64, vp]),
         "bprx_get_adam_step": (i64, [vp]),
         "bprx_adam_is_lazy": (C.c_int, [vp]),
         "bprx_sync_adam": (C.c_int, [vp, vp]),
@@ -90,6 +90,9 @@ def lib():
         "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
         "bprx_eval_users": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
         "bprx_topk": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "bprx_eval_pos": (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp]),
+        "bprx_eval_counts": (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "bprx_eval_finish": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
         "bprx_sync_check": (C.c_int, [vp, vp]),
         "bprx_probe_stream_read": (i64, [vp, i64, vp, vp]),
         "bprx_probe_stream_read_nt": (i64, [vp, i64, vp, vp]),
@@ -120,7 +123,7 @@ EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_adam_is_lazy", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
-           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
+           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_eval_pos", "bprx_eval_counts", "bprx_eval_finish", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",
            "bprx_apply_user_msgs", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]

@@ -339,10 +339,12 @@ extern "C" int bprx_bind_tables(bprx_handle *h, const bprx_tables *t) {
   return bprx_launch_adam_reset(h, h->adam_t, 0);   // every bound row counts as current at optimizer.iterations
 }
 
-extern "C" int bprx_tables_dirty(bprx_handle *h) {
+extern "C" int bprx_tables_dirty(bprx_handle *h, void *stream) {
   if (!h) return BPRX_E_INVALID;
   h->et_valid = h->p_valid = h->absmax_valid = false;
-  return h->bound ? bprx_launch_adam_reset(h, h->adam_t, 0) : BPRX_OK;   // outside values are current by definition
+  // outside values are current by definition; the bookkeeping reset is ordered on the caller's stream, behind whatever
+  // wrote the tables there (a NULL stream is synchronised instead)
+  return h->bound ? bprx_launch_adam_reset(h, h->adam_t, (hipStream_t)stream) : BPRX_OK;
 }
 
 extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
@@ -355,10 +357,10 @@ extern "C" int bprx_set_hyper(bprx_handle *h, float lr, float reg) {
   return BPRX_OK;
 }
 
-extern "C" int bprx_set_adam_step(bprx_handle *h, int64_t it) {
+extern "C" int bprx_set_adam_step(bprx_handle *h, int64_t it, void *stream) {
   if (!h || it < 0) return BPRX_E_INVALID;
   h->adam_t = it;
-  return h->bound ? bprx_launch_adam_reset(h, it, 0) : BPRX_OK;
+  return h->bound ? bprx_launch_adam_reset(h, it, (hipStream_t)stream) : BPRX_OK;
 }
 
 extern "C" int64_t bprx_get_adam_step(const bprx_handle *h) { return h ? h->adam_t : -1; }
@@ -399,11 +401,30 @@ extern "C" int bprx_score_pairs(bprx_handle *h, const int32_t *user, const int32
 extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, void *stream) {
   int rc = check_ready(h, B);
   if (rc) return rc;
-  if (B == 0) BPRX_FAIL(h, BPRX_E_INVALID, "step: empty batch");
-  if (!user || !pos || !neg) BPRX_FAIL(h, BPRX_E_INVALID, "step: null index pointer");
-  if (h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
+  if (h->pending_stage) BPRX_FAIL(h, BPRX_E_STATE, "step_begin called twice without step_end");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  if (B == 0) {
+    // A rank of a replicated-user multi-GPU step whose item shard holds no positive of this global batch: it contributes an
+    // empty message and a zero dense gradient, but takes part in every collective and takes the same optimizer step as the
+    // other replicas (bprx_pack_user_msg -> count 0, bprx_step_begin_dense -> dE|dBp = 0, bprx_apply_user_msgs, bprx_step_end).
+    if (!(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD)) BPRX_FAIL(h, BPRX_E_INVALID, "step: empty batch");
+    h->list_mode = 0; h->item_mode = 0;
+    if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
+      h->adam_t += 1;
+      const float t = (float)h->adam_t;
+      const float lr_t = h->cfg.lr * sqrtf(1.0f - powf(h->cfg.beta2, t)) / (1.0f - powf(h->cfg.beta1, t));
+      if (h->adam_lazy) {
+        if (h->adam_t - h->adam_synced >= bprx_adam_hist() - 2 && (rc = bprx_launch_adam_sync(h, h->adam_t - 1, s))) return rc;
+        if ((rc = bprx_launch_adam_catchup(h, nullptr, nullptr, nullptr, 0, lr_t, s))) return rc;   // records lr_t of this step
+      }
+      h->pend_lr = lr_t;
+    } else h->pend_lr = h->cfg.lr;
+    h->pending_B = 0; h->pending_stage = 1;
+    h->pend_u = h->pend_i = h->pend_j = nullptr;
+    return BPRX_OK;
+  }
+  if (!user || !pos || !neg) BPRX_FAIL(h, BPRX_E_INVALID, "step: null index pointer");
   // list mode: both projections over the batch's distinct items only (needs the index pass BEFORE the forward projection)
   h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
   h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
@@ -451,9 +472,14 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
 
 extern "C" int bprx_step_begin_dense(bprx_handle *h, void *stream) {
   if (!h) return BPRX_E_INVALID;
-  if (!h->pending_B || h->pending_stage != 1) BPRX_FAIL(h, BPRX_E_STATE, "step_begin_dense without step_begin_sparse");
+  if (h->pending_stage != 1) BPRX_FAIL(h, BPRX_E_STATE, "step_begin_dense without step_begin_sparse");
   hipStream_t s = (hipStream_t)stream;
   const bool vb = h->cfg.model == BPRX_MODEL_VBPR;
+  if (h->pending_B == 0) {                                 // empty batch of a replicated-user rank: zero dense gradient
+    if (vb) BPRX_HIP(h, hipMemsetAsync(h->dEp, 0, ((size_t)h->cfg.feat_dim * (h->cfg.embed_d + 1)) * sizeof(float), s));
+    h->pending_stage = 2;
+    return BPRX_OK;
+  }
   const int32_t *user = h->pend_u, *pos = h->pend_i, *neg = h->pend_j;
   const int64_t B = h->pending_B;
   const float lr_t = h->pend_lr;
@@ -478,7 +504,7 @@ extern "C" int bprx_step_begin_dense(bprx_handle *h, void *stream) {
 
 extern "C" int bprx_step_begin(bprx_handle *h, const int32_t *user, const int32_t *pos, const int32_t *neg, int64_t B, void *stream) {
   int rc = bprx_step_begin_sparse(h, user, pos, neg, B, stream);
-  if (!rc && (rc = bprx_step_begin_dense(h, stream))) h->pending_B = 0;       // a failed _begin leaves no step pending
+  if (!rc && (rc = bprx_step_begin_dense(h, stream))) { h->pending_B = 0; h->pending_stage = 0; }   // a failed _begin leaves no step pending
   return rc;
 }
 
@@ -535,7 +561,7 @@ extern "C" int bprx_dense_grad(bprx_handle *h, float **ptr, int64_t *count) {
 
 extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
   if (!h) return BPRX_E_INVALID;
-  if (!h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "step_end without step_begin");
+  if (!h->pending_stage) BPRX_FAIL(h, BPRX_E_STATE, "step_end without step_begin");
   if (h->pending_stage != 2) BPRX_FAIL(h, BPRX_E_STATE, "step_end before step_begin_dense");
   hipStream_t s = (hipStream_t)stream;
   int rc;
@@ -546,6 +572,7 @@ extern "C" int bprx_step_end(bprx_handle *h, float *loss_out, void *stream) {
   }
   int64_t B = h->pending_B;
   h->pending_B = 0;
+  h->pending_stage = 0;
   if (h->side_pending) {                                  // join the side stream (sparse optimizer pass)
     BPRX_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));
     h->side_pending = false;
@@ -573,7 +600,7 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   // default stream (cannot be captured): those take the plain path.
   const bool can_graph = (h->graph_mode == 1 || (h->graph_mode == 2 && B <= 8192)) && h->cfg.optimizer == BPRX_OPT_SGD &&
                          !h->prof && stream != nullptr && !h->side_mode && h->bound && B > 0 && B <= h->cfg.max_batch && user && pos &&
-                         neg && !h->proj_fresh && !h->pending_B;
+                         neg && !h->proj_fresh && !h->pending_stage;
   if (!can_graph) return step_plain(h, user, pos, neg, B, loss_out, stream);
   hipStream_t s = (hipStream_t)stream;
   const bool same = h->graph_key.u == user && h->graph_key.i == pos && h->graph_key.j == neg && h->graph_key.loss == loss_out &&
@@ -609,7 +636,7 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   if (!ok) {
     (void)hipGetLastError();
     h->graph_mode = 0;
-    h->pending_B = 0;
+    h->pending_B = 0; h->pending_stage = 0;
     graph_sig_apply(h, in);                                  // nothing ran: back to the state before the capture
     return rc ? rc : step_plain(h, user, pos, neg, B, loss_out, stream);
   }

@@ -157,6 +157,118 @@ __global__ __launch_bounds__(256) void k_eval_users(const float *__restrict__ S,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same metrics for an ITEM-SHARDED model (every rank holds the score columns of its own items): everything
+// k_eval_users counts is additive over item shards once the held-out items' scores are known everywhere.
+//   k_eval_pos     sp[user][t] = score of held-out item t where this rank owns it, 0 elsewhere   -> all-reduce(sum): exact
+//   k_eval_counts  per user, over the rank's own columns: #(items >= sp_t), #(train-only items >= sp_t), #(train-only items)
+//                                                                                                 -> all-reduce(sum)
+//   k_eval_finish  the reference's formulas (Evaluator.py:96-126) from the summed counts: identical to k_eval_users on the
+//                  concatenated score row, bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eval_pos(const float *__restrict__ S, int u0, int nb, int Iloc, int item_lo, int Itot,
+                                                  const int64_t *__restrict__ ev_ptr, const int32_t *__restrict__ ev_items,
+                                                  float *__restrict__ sp, int32_t *__restrict__ errflag) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)nb * EVMAX) return;
+  const int r = (int)(e / EVMAX), t = (int)(e % EVMAX);
+  const int64_t e0 = ev_ptr[u0 + r];
+  const int nev = (int)(ev_ptr[u0 + r + 1] - e0);
+  float v = 0.f;
+  if (t < nev && nev <= EVMAX) {
+    int it = ev_items[e0 + t];
+    if ((unsigned)it >= (unsigned)Itot) { *errflag = 5; it = 0; }
+    const int li = it - item_lo;
+    if ((unsigned)li < (unsigned)Iloc) v = S[(size_t)r * Iloc + li];
+  }
+  sp[e] = v;
+}
+
+__global__ __launch_bounds__(256) void k_eval_counts(const float *__restrict__ S, int u0, int Iloc, int item_lo, int Itot,
+                                                     const int64_t *__restrict__ tr_ptr, const int32_t *__restrict__ tr_items,
+                                                     const int64_t *__restrict__ ev_ptr, const int32_t *__restrict__ ev_items,
+                                                     const float *__restrict__ spg, int32_t *__restrict__ counts) {
+  __shared__ float sp[EVMAX];
+  __shared__ int ev[EVMAX];
+  __shared__ int cnt_all[EVMAX], cnt_sub[EVMAX];
+  __shared__ int n_tr_only;
+  const int u = u0 + blockIdx.x, tid = threadIdx.x;
+  const float *s = S + (size_t)blockIdx.x * Iloc;
+  int32_t *o = counts + (size_t)blockIdx.x * (2 * EVMAX + 1);
+  const int64_t e0 = ev_ptr[u];
+  const int nev = (int)(ev_ptr[u + 1] - e0);
+  if (nev <= 0 || nev > EVMAX) {
+    for (int q = tid; q < 2 * EVMAX + 1; q += 256) o[q] = 0;
+    return;
+  }
+  if (tid < EVMAX) { cnt_all[tid] = 0; cnt_sub[tid] = 0; }
+  if (tid < nev) {
+    int it = ev_items[e0 + tid];
+    if ((unsigned)it >= (unsigned)Itot) it = 0;                    // (reported by k_eval_pos)
+    ev[tid] = it;
+    sp[tid] = spg[(size_t)blockIdx.x * EVMAX + tid];
+  }
+  if (tid == 0) n_tr_only = 0;
+  __syncthreads();
+  for (int t = 0; t < nev; ++t) {
+    const float spt = sp[t];
+    int loc = 0;
+    for (int i = tid; i < Iloc; i += 256) loc += s[i] >= spt ? 1 : 0;
+    if (loc) atomicAdd(&cnt_all[t], loc);
+  }
+  const int64_t t0 = tr_ptr[u];
+  const int ntr = (int)(tr_ptr[u + 1] - t0);
+  for (int q = tid; q < ntr; q += 256) {
+    const int it = tr_items[t0 + q];
+    const int li = it - item_lo;
+    if ((unsigned)li >= (unsigned)Iloc) continue;                  // another rank's column (or out of range: nobody's)
+    bool is_ev = false;
+    for (int t = 0; t < nev; ++t) is_ev |= ev[t] == it;
+    if (is_ev) continue;
+    atomicAdd(&n_tr_only, 1);
+    const float v = s[li];
+    for (int t = 0; t < nev; ++t)
+      if (v >= sp[t]) atomicAdd(&cnt_sub[t], 1);
+  }
+  __syncthreads();
+  if (tid < EVMAX) { o[tid] = tid < nev ? cnt_all[tid] : 0; o[EVMAX + tid] = tid < nev ? cnt_sub[tid] : 0; }
+  if (tid == 0) o[2 * EVMAX] = n_tr_only;
+}
+
+__global__ __launch_bounds__(256) void k_eval_finish(int u0, int nb, int Itot, const int64_t *__restrict__ ev_ptr,
+                                                     const float *__restrict__ spg, const int32_t *__restrict__ counts, int K,
+                                                     double *__restrict__ out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nb) return;
+  double *o = out + (size_t)r * 5;
+  const int nev = (int)(ev_ptr[u0 + r + 1] - ev_ptr[u0 + r]);
+  if (nev <= 0 || nev > EVMAX) {
+    o[0] = nev <= 0 ? -1.0 : -2.0; o[1] = o[2] = o[3] = o[4] = 0.0;
+    return;
+  }
+  const float *sp = spg + (size_t)r * EVMAX;
+  const int32_t *c = counts + (size_t)r * (2 * EVMAX + 1);
+  long long position = 0;
+  int hits = 0;
+  const long long nneg = (long long)Itot - c[2 * EVMAX] - nev;
+  const long long topn = (long long)K < nneg + nev ? (long long)K : nneg + nev;
+  for (int t = 0; t < nev; ++t) {
+    int ge_ev = 0, before = 0;
+    for (int q = 0; q < nev; ++q) {
+      if (sp[q] >= sp[t]) ++ge_ev;
+      if (q != t && (sp[q] > sp[t] || (sp[q] == sp[t] && q < t))) ++before;
+    }
+    const long long neg_ge = (long long)c[t] - c[EVMAX + t] - ge_ev;             // Evaluator.py:96-98
+    position += neg_ge;
+    if (neg_ge + before < topn) ++hits;                                          // heapq.nlargest membership, :104-115
+  }
+  o[0] = hits > 0 ? 1.0 : 0.0;
+  o[1] = topn > 0 ? (double)hits / (double)topn : 0.0;
+  o[2] = (double)hits / (double)nev;
+  o[3] = 1.0 - (double)position / ((double)nneg * (double)nev);
+  o[4] = position < K ? log(2.0) / log((double)position + 2.0) : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Evaluator.store_recommendation on the device (Evaluator.py:225-239): per user, the train items are masked with -inf
 // IN the score row (as the reference does: results[u][training_list[u]] = -np.inf) and the K largest scores are
 // selected.  One workgroup per user: radix select of the K-th largest key over the row (four 8-bit histogram passes on
@@ -295,5 +407,45 @@ extern "C" int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const flo
   hipLaunchKernelGGL(k_eval_users, dim3(u1 - u0), dim3(256), 0, (hipStream_t)stream, scores, u0, h->cfg.num_items, train_ptr,
                      train_items, eval_ptr, eval_items, K, out, h->errflag);
   BPRX_LAUNCH_CHECK(h, "k_eval_users");
+  return BPRX_OK;
+}
+
+// ---- item-sharded evaluation (see k_eval_pos / k_eval_counts / k_eval_finish) ----
+extern "C" int bprx_eval_pos(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, int32_t item_lo, int32_t items_total,
+                             const int64_t *eval_ptr, const int32_t *eval_items, float *sp, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (u0 < 0 || u0 > u1 || !scores || !eval_ptr || !eval_items || !sp || item_lo < 0 || items_total <= 0)
+    BPRX_FAIL(h, BPRX_E_INVALID, "eval_pos: bad argument");
+  if (u0 == u1) return BPRX_OK;
+  const int nb = u1 - u0;
+  hipLaunchKernelGGL(k_eval_pos, dim3((unsigned)(((int64_t)nb * EVMAX + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, u0,
+                     nb, h->cfg.num_items, item_lo, items_total, eval_ptr, eval_items, sp, h->errflag);
+  BPRX_LAUNCH_CHECK(h, "k_eval_pos");
+  return BPRX_OK;
+}
+
+extern "C" int bprx_eval_counts(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, int32_t item_lo, int32_t items_total,
+                                const int64_t *train_ptr, const int32_t *train_items, const int64_t *eval_ptr,
+                                const int32_t *eval_items, const float *sp, int32_t *counts, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (u0 < 0 || u0 > u1 || !scores || !train_ptr || !train_items || !eval_ptr || !eval_items || !sp || !counts || item_lo < 0)
+    BPRX_FAIL(h, BPRX_E_INVALID, "eval_counts: bad argument");
+  if (u0 == u1) return BPRX_OK;
+  hipLaunchKernelGGL(k_eval_counts, dim3(u1 - u0), dim3(256), 0, (hipStream_t)stream, scores, u0, h->cfg.num_items, item_lo,
+                     items_total, train_ptr, train_items, eval_ptr, eval_items, sp, counts);
+  BPRX_LAUNCH_CHECK(h, "k_eval_counts");
+  return BPRX_OK;
+}
+
+extern "C" int bprx_eval_finish(bprx_handle *h, int32_t u0, int32_t u1, int32_t items_total, const int64_t *eval_ptr,
+                                const float *sp, const int32_t *counts, int32_t K, double *out, void *stream) {
+  if (!h) return BPRX_E_INVALID;
+  if (u0 < 0 || u0 > u1 || !eval_ptr || !sp || !counts || !out || K <= 0 || items_total <= 0)
+    BPRX_FAIL(h, BPRX_E_INVALID, "eval_finish: bad argument");
+  if (u0 == u1) return BPRX_OK;
+  const int nb = u1 - u0;
+  hipLaunchKernelGGL(k_eval_finish, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u0, nb, items_total,
+                     eval_ptr, sp, counts, K, out);
+  BPRX_LAUNCH_CHECK(h, "k_eval_finish");
   return BPRX_OK;
 }

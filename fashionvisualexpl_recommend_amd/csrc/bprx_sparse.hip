@@ -727,7 +727,8 @@ __global__ __launch_bounds__(256) void k_adam_catchup(AdamTables T, AdamLazy a, 
   const bool valid = job < 3 * B;
   const int kind = valid ? (int)(job / B) : 0;
   const int64_t b = valid ? job - (int64_t)kind * B : 0;
-  const int row = kind == 0 ? clamp_quiet(user[b], T.U) : clamp_quiet(kind == 1 ? pos[b] : neg[b], T.I);
+  int row = 0;                                             // (B == 0: an empty step of a replicated-user rank only records lr_t)
+  if (valid) row = kind == 0 ? clamp_quiet(user[b], T.U) : clamp_quiet(kind == 1 ? pos[b] : neg[b], T.I);
   int32_t *last = kind == 0 ? T.lastU + row : T.lastI + row;
   int old = t;
   if (valid && lane == 0) {
@@ -1862,13 +1863,15 @@ extern "C" int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap) {
 }
 
 extern "C" int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream) {
-  if (!h || !user || !msg || B <= 0 || cap <= 0) return BPRX_E_INVALID;
+  if (!h || !msg || B < 0 || cap <= 0 || (B > 0 && !user)) return BPRX_E_INVALID;
   if (!(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD)) BPRX_FAIL(h, BPRX_E_STATE, "pack_user_msg needs BPRX_FLAG_EXPORT_USER_GRAD");
-  if (!h->pending_B) BPRX_FAIL(h, BPRX_E_STATE, "pack_user_msg outside a step (after bprx_step_begin[_sparse])");
+  if (!h->pending_stage) BPRX_FAIL(h, BPRX_E_STATE, "pack_user_msg outside a step (after bprx_step_begin[_sparse])");
+  if (B != h->pending_B) BPRX_FAIL(h, BPRX_E_INVALID, "pack_user_msg: B differs from the pending step's");
   hipStream_t s = (hipStream_t)stream;
   const int k = h->cfg.embed_k, d = h->cfg.embed_d;
   const dim3 grid((unsigned)((B + 255) / 256));
-  if (vec_ok(h) && ((uintptr_t)msg & 15) == 0)
+  if (B == 0) BPRX_HIP(h, hipMemsetAsync(msg, 0, 4 * sizeof(float), s));          // an empty message: count 0
+  else if (vec_ok(h) && ((uintptr_t)msg & 15) == 0)
     hipLaunchKernelGGL(k_pack_user_msg<true>, grid, dim3(256), 0, s, user, B, h->cfg.num_users, k, d, (int)cap, h->flagU, h->dGu,
                        h->dTu, msg, h->msg_cursor, h->errflag);
   else
@@ -2130,7 +2133,7 @@ int bprx_launch_adam_catchup(bprx_handle *h, const int32_t *u, const int32_t *i,
   const AdamTables T = make_adam_tables(h);
   const AdamLazy al = {h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, h->lr_hist};
   BprxProfScope ps(h, BPRX_PHASE_ADAM_CATCHUP, s);
-  DISPATCH_G(G, vec, k_adam_catchup, grid_for(3 * B, G), s, T, al, u, i, j, B, (int)h->adam_t, lr_t, h->lr_hist);
+  DISPATCH_G(G, vec, k_adam_catchup, grid_for(B ? 3 * B : 1, G), s, T, al, u, i, j, B, (int)h->adam_t, lr_t, h->lr_hist);
   BPRX_LAUNCH_CHECK(h, "k_adam_catchup");
   return BPRX_OK;
 }

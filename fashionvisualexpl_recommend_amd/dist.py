@@ -313,8 +313,12 @@ class ReplicatedUserVBPR:
             return None
         return dist.all_reduce(t, group=self.group, async_op=True)
 
-    def step(self, u_global, i_local, j_local, want_loss=False):
+    def step(self, u_global, i_local, j_local, want_loss=False, loss_out=None, loss_index=0):
+        """One global step.  A rank whose item shard holds no positive of this batch passes EMPTY index tensors: it sends a
+        count-0 message and a zero dense gradient and still takes part in every collective (bprx_step_begin_sparse, B = 0).
+        loss_out / loss_index: see Engine.step_end."""
         eng = self.eng
+        end = lambda: eng.step_end(want_loss=want_loss, loss_out=loss_out, loss_index=loss_index)
         if not self.overlap:
             eng.step_begin(u_global, i_local, j_local)
             eng.pack_user_msg(u_global, self.cap, self.msg)
@@ -324,7 +328,7 @@ class ReplicatedUserVBPR:
                 if w is not None:
                     w.wait()
             eng.apply_user_msgs(self.msgs, self.world, self.cap, -self.lr)
-            return eng.step_end(want_loss=want_loss)
+            return end()
         eng.step_begin_sparse(u_global, i_local, j_local)          # ... per-triplet gradients: user rows are final
         eng.pack_user_msg(u_global, self.cap, self.msg)
         wm = self._all_gather(self.msgs, self.msg)                  # in flight beside:
@@ -340,7 +344,7 @@ class ReplicatedUserVBPR:
             wd.wait()
         if self.dense_reduce == "gather":
             eng.sum_dense_parts(self.dparts, self.world)
-        return eng.step_end(want_loss=want_loss)
+        return end()
 
 
 RowExchange = UserRowExchange      # the routing is the same whichever table is the remote one

@@ -14,7 +14,7 @@ PARAM_NAMES = ("Gu", "Gi", "Bi", "Tu", "E", "Bp")
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if (t is None or t.numel() == 0) else C.c_void_p(t.data_ptr())
 
 
 def _stream():
@@ -128,7 +128,7 @@ class Engine:
     def tables_dirty(self):
         """Call after writing any bound table from outside the library (bprx_tables_dirty): the handle reuses images
         derived from E/Bp (their bf16/fp8 copy, the item projections) until a step changes them."""
-        _ffi.check(self.h, self.lib.bprx_tables_dirty(self.h))
+        _ffi.check(self.h, self.lib.bprx_tables_dirty(self.h, _stream()))
 
     def params(self):
         return {n: self.t[n] for n in PARAM_NAMES if self.t.get(n) is not None}
@@ -142,7 +142,7 @@ class Engine:
 
     @adam_step.setter
     def adam_step(self, v):
-        _ffi.check(self.h, self.lib.bprx_set_adam_step(self.h, int(v)))
+        _ffi.check(self.h, self.lib.bprx_set_adam_step(self.h, int(v), _stream()))
 
     # ---- hot path ------------------------------------------------------------------------------------------------
     def score_pairs(self, user, item):
@@ -229,9 +229,14 @@ class Engine:
     def clear_user_grad(self, n_rows):
         _ffi.check(self.h, self.lib.bprx_clear_user_grad(self.h, int(n_rows), _stream()))
 
-    def step_end(self, want_loss=True):
-        _ffi.check(self.h, self.lib.bprx_step_end(self.h, _ptr(self._loss) if want_loss else None, _stream()))
-        return self._loss
+    def step_end(self, want_loss=True, loss_out=None, loss_index=0):
+        """loss_out / loss_index: as in step() -- the loss lands in element `loss_index` of a device tensor."""
+        if loss_out is not None:
+            lp = C.c_void_p(loss_out.data_ptr() + 4 * int(loss_index))
+        else:
+            lp = _ptr(self._loss) if want_loss else None
+        _ffi.check(self.h, self.lib.bprx_step_end(self.h, lp, _stream()))
+        return self._loss if loss_out is None else loss_out
 
     def score_block(self, u0, u1, out=None):
         if out is None:
@@ -244,6 +249,26 @@ class Engine:
         out = torch.empty((u1 - u0, 5), dtype=torch.float64, device=self.device)
         _ffi.check(self.h, self.lib.bprx_eval_users(self.h, u0, u1, _ptr(scores), _ptr(train_csr[0]), _ptr(train_csr[1]),
                                                     _ptr(eval_csr[0]), _ptr(eval_csr[1]), int(K), _ptr(out), _stream()))
+        return out
+
+    # ---- item-sharded evaluation: counts that are additive over item shards (include/bprx.h) ----------------------
+    def eval_pos(self, u0, u1, scores, item_lo, items_total, eval_csr):
+        sp = torch.empty((u1 - u0, 32), dtype=torch.float32, device=self.device)
+        _ffi.check(self.h, self.lib.bprx_eval_pos(self.h, u0, u1, _ptr(scores), int(item_lo), int(items_total),
+                                                  _ptr(eval_csr[0]), _ptr(eval_csr[1]), _ptr(sp), _stream()))
+        return sp
+
+    def eval_counts(self, u0, u1, scores, item_lo, items_total, train_csr, eval_csr, sp):
+        counts = torch.empty((u1 - u0, 65), dtype=torch.int32, device=self.device)
+        _ffi.check(self.h, self.lib.bprx_eval_counts(self.h, u0, u1, _ptr(scores), int(item_lo), int(items_total),
+                                                     _ptr(train_csr[0]), _ptr(train_csr[1]), _ptr(eval_csr[0]),
+                                                     _ptr(eval_csr[1]), _ptr(sp), _ptr(counts), _stream()))
+        return counts
+
+    def eval_finish(self, u0, u1, items_total, eval_csr, sp, counts, K):
+        out = torch.empty((u1 - u0, 5), dtype=torch.float64, device=self.device)
+        _ffi.check(self.h, self.lib.bprx_eval_finish(self.h, u0, u1, int(items_total), _ptr(eval_csr[0]), _ptr(sp), _ptr(counts),
+                                                     int(K), _ptr(out), _stream()))
         return out
 
     def topk(self, u0, u1, scores, train_csr, K):

@@ -94,10 +94,9 @@ class BPRMF(RecommenderModel):
         self._alias()
 
     def _alias(self):
-        for n, v in self.engine.params().items():
-            setattr(self, n, v)
-        if "F" in self.engine.t:
-            self.F = self.engine.t["F"]
+        """The reference's attribute surface (model.Gu, .Gi, .Bi, .Tu, .F, .E, .Bp) is served by the class properties below:
+        they go through engine.t, which first brings every row up to date when adam_tf23 runs lazily (bprx_sync_adam) -- a
+        raw alias of the tensor would show rows that have not been replayed yet."""
 
     # ---- BPRMF.py:55-76 ------------------------------------------------------------------------------------------
     def call(self, inputs, training=None, mask=None):
@@ -149,7 +148,16 @@ class BPRMF(RecommenderModel):
         best_epoch = self.restore_epochs
         best_epoch_print = 'No best epoch found!'
         results = {}
-        next_batch = self.data.next_triple_batch(self.engine.device)
+        steps_total = (sum(len(pos) for pos in self.data.training_list) // self.params.batch_size) * self.params.epochs
+        if getattr(self.params, "sampler", "ref_stream") == "philox":
+            # --sampler philox: the device epoch walk (the reference's visiting order as a stateless Philox stream; bit-exact
+            # CPU twin in the oracle) instead of the host MT19937 stream -- no index upload per step
+            from .engine import EpochWalkSampler
+            smp = EpochWalkSampler(self.data.training_list, self.num_items, device=self.engine.device,
+                                   seed=getattr(self.params, "init_seed", 0))
+            next_batch = (smp.sample(self.params.batch_size) for _ in range(steps_total))
+        else:
+            next_batch = self.data.next_triple_batch(self.engine.device)
         steps = 0
         loss = 0
         it = 1
@@ -208,6 +216,14 @@ class BPRMF(RecommenderModel):
             max_metrics['hr'], max_metrics['p'], max_metrics['r'], max_metrics['auc'], max_metrics['ndcg']))
         self.results = results
         return results
+
+
+def _table_property(name):
+    return property(lambda self: self.engine.t[name], doc="bound tensor %s (current: lazy adam_tf23 rows are replayed first)" % name)
+
+
+for _n in ("Gu", "Gi", "Bi", "Tu", "F", "E", "Bp"):
+    setattr(BPRMF, _n, _table_property(_n))
 
 
 class VBPR(BPRMF):

@@ -11,10 +11,16 @@ backend "nccl" == RCCL on ROCm; "gloo" for CPU-side tests and one-GPU rehearsals
   reference's GLOBAL max-abs normalisation (visual_loader_mixin.py:30) becomes a max-abs per shard + all-reduce(MAX).
 --shard user  (BPRMF, configs[2]): users are range-partitioned, item rows travel by all-to-all (UserShardedBPRMF).
 
-Evaluation gathers the ranks' score columns per user block on rank 0 and runs the reference's metric definitions there
-(evaluator._eval_block); outputs (epoch lines, results dict, recs TSV) are written by rank 0 only.
+Evaluation runs on the devices: every rank scores its own item columns per user block and counts there (bprx_eval_pos /
+bprx_eval_counts: what the reference's metrics count is additive over item shards); two small all-reduces per block carry the
+held-out items' scores and the counts, and every rank finishes the same metrics (bprx_eval_finish) -- equal to the single-GPU
+evaluator on the concatenated score row.  Rank 0 writes the reference's outputs (epoch lines, results pickle, weights of the
+replicated tables + the gathered item shards, recs TSV of the last and of the best epoch; BPRMF.py:152-183).
 """
+import contextlib
+import io
 import os
+import pickle
 from time import time
 
 import numpy as np
@@ -59,6 +65,7 @@ class ShardedVBPR:
     def __init__(self, data, params, features=None, group=None):
         from .dist import ReplicatedUserVBPR
         from .engine import EpochWalkSampler
+        from .evaluator import Evaluator
         self.data, self.params, self.group = data, params, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.num_users, self.num_items = data.num_users, data.num_items
@@ -82,16 +89,35 @@ class ShardedVBPR:
                                     optimizer=getattr(params, "optimizer", "adam_tf23"),
                                     dense_reduce=getattr(params, "dense_reduce", "gather"))
         self.engine = self.m.eng
+        self.host_staged = dist.get_backend(group) != "nccl"              # gloo (tests, one-GPU rehearsals): collectives on host copies
         lists = local_positive_lists(data.training_list, self.num_users, self.lo, self.hi)
         self.local_pos = sum(len(l) for l in lists)
         n = torch.tensor([self.local_pos], dtype=torch.int64)
         dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
         self.steps_per_epoch = max(1, int(n.item()) // self.batch)     # every rank steps as often as the fullest shard
+        # a rank whose shard holds no positive still takes every step (with an empty batch: dist.ReplicatedUserVBPR.step)
         self.sampler = EpochWalkSampler(lists, self.hi - self.lo, device=self.engine.device,
                                         seed=getattr(params, "init_seed", 0) + 7919 * self.rank) if self.local_pos else None
         self.directory_parameters = f'batch_{params.batch_size}-D_{d}-K_{k}-lr_{params.lr}-reg_{params.reg}-W_{self.world}'
+        # device CSRs with GLOBAL item ids for the shard-additive evaluation (the Evaluator's own helpers)
+        ev = Evaluator(self, data, params.top_k)
+        ev._metrics_device_csr()
+        self._csr = ev._csr
+        self.evaluator = _ShardedEvaluator(self, data, params.top_k)
 
-    # ---- scores: every rank's item columns, gathered on rank 0 ------------------------------------------------
+    # ---- collectives on device tensors (RCCL), or through host copies under gloo ----------------------------------
+    def _all_reduce_sum(self, t):
+        if self.world == 1:
+            return t
+        if self.host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    # ---- scores: every rank's item columns, gathered on rank 0 (output files only: never inside the training loop) ------
     def predict_block(self, u0, u1):
         loc = self.engine.score_block(u0, u1).cpu()                    # [nb, I_shard]
         sh = (self.num_items + self.world - 1) // self.world
@@ -104,40 +130,155 @@ class ShardedVBPR:
         return torch.cat(parts, dim=1)[:, :self.num_items].numpy()
 
     def metrics(self, K, user_block=4096):
-        from .evaluator import _eval_block
-        res_t, res_v = [], []
-        val = bool(self.data.validation_list)
+        """The ten means of Evaluator.py:189-193 on the devices; every rank returns the same dict."""
+        eng, out = self.engine, {}
+        rows = {"test": [], "val": []}
         for u0 in range(0, self.num_users, user_block):
             u1 = min(self.num_users, u0 + user_block)
-            sc = self.predict_block(u0, u1)
-            if self.rank == 0:
-                res_t += _eval_block(sc, u0, self.data.training_list, self.data.test_list, K)
-                if val:
-                    res_v += _eval_block(sc, u0, self.data.training_list, self.data.validation_list, K)
-        if self.rank != 0:
-            return None
-        out = dict(zip(("hr_t", "p_t", "r_t", "auc_t", "ndcg_t"), np.array(res_t).mean(axis=0).tolist()))
-        if val:
-            out.update(zip(("hr_v", "p_v", "r_v", "auc_v", "ndcg_v"), np.array(res_v).mean(axis=0).tolist()))
+            sc = eng.score_block(u0, u1)                               # this rank's columns only
+            for key in ("test", "val"):
+                if self._csr[key] is None:
+                    continue
+                sp = self._all_reduce_sum(eng.eval_pos(u0, u1, sc, self.lo, self.num_items, self._csr[key]))
+                cn = self._all_reduce_sum(eng.eval_counts(u0, u1, sc, self.lo, self.num_items, self._csr["train"],
+                                                          self._csr[key], sp))
+                rows[key].append(eng.eval_finish(u0, u1, self.num_items, self._csr[key], sp, cn, K))
+        for key, suf in (("test", "_t"), ("val", "_v")):
+            if not rows[key]:
+                continue
+            r = torch.cat(rows[key]).cpu().numpy()
+            if (r[:, 0] == -2).any():
+                raise NotImplementedError("more than 32 held-out items per user: not supported by the sharded evaluator")
+            r = r[r[:, 0] >= 0]
+            hr, p, rr, auc, ndcg = r.mean(axis=0).tolist()
+            out.update({"hr" + suf: hr, "p" + suf: p, "r" + suf: rr, "auc" + suf: auc, "ndcg" + suf: ndcg})
         return out
 
-    # ---- BPRMF.py:127-165 with one step = one global batch of world x batch_size triplets -----------------------
-    def train(self):
-        results, dev = {}, self.engine.device
-        empty = torch.zeros(0, dtype=torch.int32, device=dev)
-        for it in range(1, self.params.epochs + 1):
-            start, loss = time(), 0.0
-            for _ in range(self.steps_per_epoch):
-                u, i, j = self.sampler.sample(self.batch) if self.sampler is not None else (empty, empty, empty)
-                loss += float(self.m.step(u, i, j, want_loss=True).item())
-            m = self.metrics(self.params.top_k)
+    # ---- snapshots: the reference deep-copies / checkpoints the whole model (BPRMF.py:156-160,177-179) ---------------
+    def local_state(self):
+        """This rank's tensors (replicated tables, its item rows, Adam slots) -- what `best model` tracking keeps per rank."""
+        sd = {n: v.detach().clone() for n, v in self.engine.t.items() if n != "F"}
+        sd["adam_step"] = self.engine.adam_step
+        return sd
+
+    def load_local_state(self, sd):
+        for n, v in sd.items():
+            if n == "adam_step":
+                self.engine.adam_step = v
+            else:
+                self.engine.t[n].copy_(v)
+        self.engine.tables_dirty()
+
+    def full_state(self, sd=None):
+        """The whole model on rank 0 (None elsewhere): replicated tables as they are, item-sharded ones gathered by rows."""
+        sd = self.local_state() if sd is None else sd
+        sh = (self.num_items + self.world - 1) // self.world
+        out = {}
+        for n, v in sd.items():
+            if n == "adam_step" or not (n.endswith("Gi") or n.endswith("Bi")):
+                out[n] = v if n == "adam_step" else v.cpu()
+                continue
+            loc = v.cpu()
+            pad = torch.zeros((sh,) + tuple(loc.shape[1:]), dtype=loc.dtype)
+            pad[:loc.shape[0]] = loc
+            parts = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(pad, parts, dst=0, group=self.group)
             if self.rank == 0:
-                results[it] = {"hr_v": m.get("hr_v", 0.0), "auc_v": m.get("auc_v", 0.0), "p_v": m.get("p_v", 0.0),
-                               "r_v": m.get("r_v", 0.0), "ndcg_v": m.get("ndcg_v", 0.0), "hr_t": m["hr_t"],
-                               "auc_t": m.get("auc_v", 0.0), "p_t": m["p_t"], "r_t": m["r_t"], "ndcg_t": m["ndcg_t"]}
-                print('Epoch {0}/{1} \tLoss (rank 0 shard): {2:.3f} \tTrain+Eval Time: {3:.1f}s \tHR@{4} (Test): {5:.4f} '
-                      '\tnDCG (Test): {6:.4f}'.format(it, self.params.epochs, loss / self.steps_per_epoch, time() - start,
-                                                       self.params.top_k, m["hr_t"], m["ndcg_t"]))
+                out[n] = torch.cat(parts, dim=0)[:self.num_items]
+        return out if self.rank == 0 else None
+
+    def store_recommendation(self, path):
+        """Evaluator.py:225-239 on the gathered score blocks (rank 0 writes; every rank takes part in the gathers)."""
+        K = self.params.top_k
+        out = open(path, 'w') if self.rank == 0 else None
+        try:
+            for u0 in range(0, self.num_users, 4096):
+                u1 = min(self.num_users, u0 + 4096)
+                sc = self.predict_block(u0, u1)
+                if self.rank != 0:
+                    continue
+                for r in range(sc.shape[0]):
+                    u, row = u0 + r, sc[r]
+                    row[self.data.training_list[u]] = -np.inf
+                    top_k_id = row.argsort()[-K:][::-1]
+                    for i, value in enumerate(top_k_id):
+                        out.write(str(u) + '\t' + str(value) + '\t' + str(row[top_k_id][i]) + '\n')
+        finally:
+            if out is not None:
+                out.close()
+
+    # ---- BPRMF.py:127-192 with one step = one global batch of world x batch_size triplets ---------------------------
+    def train(self):
+        params, dev = self.params, self.engine.device
+        max_metrics = {'hr': 0, 'p': 0, 'r': 0, 'auc': 0, 'ndcg': 0}
+        best_state, best_epoch, best_epoch_print = None, getattr(params, "restore_epochs", 1), 'No best epoch found!'
+        results = {}
+        rec = getattr(params, "rec", "vbpr")
+        wdir = os.path.join(configs.weight_dir(), params.dataset, rec)
+        rdir = os.path.join(configs.results_dir(), params.dataset, rec)
+        if self.rank == 0:
+            os.makedirs(wdir, exist_ok=True)
+            os.makedirs(rdir, exist_ok=True)
+        empty = torch.zeros(0, dtype=torch.int32, device=dev)
+        loss_buf = torch.zeros(self.steps_per_epoch, dtype=torch.float32, device=dev)      # read once per epoch: no per-step sync
+        verbose = getattr(params, "verbose", -1)
+        best_metric = getattr(params, "best_metric", "ndcg")
+        if self.rank == 0:
+            print('Start training...')
+        for it in range(1, params.epochs + 1):
+            start = time()
+            for s in range(self.steps_per_epoch):
+                u, i, j = self.sampler.sample(self.batch) if self.sampler is not None else (empty, empty, empty)
+                self.m.step(u, i, j, loss_out=loss_buf, loss_index=s)
+            loss = float(loss_buf.double().sum().item())
+            epoch_text = 'Epoch {0}/{1} \tLoss (rank 0 shard): {2:.3f}'.format(it, params.epochs, loss / self.steps_per_epoch)
+            epoch_print = self.evaluator.eval(it, results, epoch_text, start)               # identical on every rank
+            for metric in max_metrics.keys():                                               # BPRMF.py:152-156
+                if max_metrics[metric] <= results[it][metric + '_v']:
+                    max_metrics[metric] = results[it][metric + '_v']
+                    if metric == best_metric:
+                        best_epoch, best_state, best_epoch_print = it, self.local_state(), epoch_print
+            if (it % verbose == 0 or it == 1) and verbose != -1:
+                full = self.full_state()
+                if self.rank == 0:
+                    torch.save(full, os.path.join(wdir, f'weights-{it}-{self.directory_parameters}.pt'))
         self.engine.sync_check()
+        last = params.epochs
+        if self.rank == 0:
+            print('Training end...')
+        self.store_recommendation(os.path.join(rdir, f'recs-{last}-{self.directory_parameters}.tsv'))
+        if self.rank == 0:
+            with open(os.path.join(rdir, f'results-metrics-{self.directory_parameters}') + '.pkl', 'wb') as f:
+                pickle.dump(results, f)                                                     # utils/write.py:14-22
+            print("Store Best Model at Epoch {0}".format(best_epoch))
+            print(best_epoch_print)
+        last_state = self.local_state()
+        if best_state is not None:
+            full = self.full_state(best_state)
+            if self.rank == 0:
+                torch.save(full, os.path.join(wdir, f'best-weights-{best_epoch}-{self.directory_parameters}.pt'))
+            self.load_local_state(best_state)
+        self.store_recommendation(os.path.join(rdir, f'best-recs-{best_epoch}-{self.directory_parameters}.tsv'))
+        self.load_local_state(last_state)
+        if self.rank == 0:
+            print('End Store Best Model!')
+            print('Best Values for Each Metric:\nHR\tPrec\tRec\tAUC\tnDCG\n{}\t{}\t{}\t{}\t{}\n'.format(
+                max_metrics['hr'], max_metrics['p'], max_metrics['r'], max_metrics['auc'], max_metrics['ndcg']))
         self.results = results
         return results
+
+
+from .evaluator import Evaluator as _Evaluator                                              # noqa: E402
+
+
+class _ShardedEvaluator(_Evaluator):
+    """The reference's eval() surface (epoch line, results dict with its key aliasing) over the shard-additive device metrics;
+    only rank 0 prints."""
+
+    def metrics(self):
+        return self.model.metrics(self.k)
+
+    def eval(self, epoch=0, results=None, epoch_text='', start_time=0):
+        quiet = contextlib.redirect_stdout(io.StringIO()) if self.model.rank != 0 else contextlib.nullcontext()
+        with quiet:
+            return super().eval(epoch, results, epoch_text, start_time)

@@ -120,10 +120,11 @@ BPRX_API int bprx_bind_tables(bprx_handle *h, const bprx_tables *t);
    deep-copies / checkpoints the whole model, BPRMF.py:156-160,177-179).  The handle keeps images DERIVED from them across
    calls -- the bf16/fp8 image of [E|Bp]^T and the item projections P = F.[E|Bp] that bprx_score_block / bprx_score_pairs
    reuse until a step changes E/Bp -- so after writing any bound table from outside the library call bprx_tables_dirty()
-   before the next library call.  (bprx_bind_tables implies it.) */
-BPRX_API int bprx_tables_dirty(bprx_handle *h);
+   before the next library call.  (bprx_bind_tables implies it.)  `stream`: the stream the outside writes were enqueued on --
+   the lazy-Adam bookkeeping reset is ordered behind them there (NULL: the null stream, synchronised). */
+BPRX_API int bprx_tables_dirty(bprx_handle *h, void *stream);
 BPRX_API int bprx_set_hyper(bprx_handle *h, float lr, float reg);           /* train_rec.py:69 (args.reg = reg) */
-BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations);         /* optimizer.iterations (resume) */
+BPRX_API int bprx_set_adam_step(bprx_handle *h, int64_t iterations, void *stream);   /* optimizer.iterations (resume); stream as above */
 /* adam_tf23 is implemented LAZILY but exactly: TF-2.3's Adam moves every row of every table every step (non-lazy sparse
    apply, BPRMF.py:123 / VBPR.py:142); here a row that received no gradient is brought up to date -- by replaying the
    skipped steps with the arithmetic of the whole-table sweep, bit for bit -- when it is next read.  The library does that
@@ -222,6 +223,23 @@ BPRX_API int bprx_profile_read(bprx_handle *h, double *ms, int64_t *launches);
 BPRX_API int bprx_eval_users(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, const int64_t *train_ptr,
                              const int32_t *train_items, const int64_t *eval_ptr, const int32_t *eval_items, int32_t K,
                              double *out, void *stream);
+
+/* The same metrics for an ITEM-SHARDED model (train_rec --world_size N --shard item): every rank holds the score columns of its
+   own items [item_lo, item_lo + num_items) of items_total; `scores` = bprx_score_block of the same user range on that rank.
+   The CSR lists carry GLOBAL item ids.  Everything Evaluator._eval_by_user counts is additive over item shards:
+     bprx_eval_pos     sp fp32 [(u1-u0), 32]: the score of held-out item t where this rank owns it, 0 elsewhere
+                       -> the caller all-reduces (sum) sp: exact, one rank contributes each value
+     bprx_eval_counts  counts int32 [(u1-u0), 65]: per held-out item #(own items >= sp_t) [0..32), #(own train-only items >= sp_t)
+                       [32..64), and #(own train-only items) [64]        -> the caller all-reduces (sum) counts
+     bprx_eval_finish  out double [(u1-u0), 5] from the summed counts, as bprx_eval_users (same markers -1 / -2): equal to
+                       bprx_eval_users on the concatenated score row (Evaluator.py:96-126). */
+BPRX_API int bprx_eval_pos(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, int32_t item_lo, int32_t items_total,
+                           const int64_t *eval_ptr, const int32_t *eval_items, float *sp, void *stream);
+BPRX_API int bprx_eval_counts(bprx_handle *h, int32_t u0, int32_t u1, const float *scores, int32_t item_lo, int32_t items_total,
+                              const int64_t *train_ptr, const int32_t *train_items, const int64_t *eval_ptr,
+                              const int32_t *eval_items, const float *sp, int32_t *counts, void *stream);
+BPRX_API int bprx_eval_finish(bprx_handle *h, int32_t u0, int32_t u1, int32_t items_total, const int64_t *eval_ptr,
+                              const float *sp, const int32_t *counts, int32_t K, double *out, void *stream);
 
 /* Build-time table of the software-pipelined forward-projection instantiations that hipcc compiled free of scratch,
    spills and stray AGPR use (only those are ever launched; every other shape falls back to the plain kernel).

@@ -119,6 +119,66 @@ def test_snapshot_and_restore_with_pending_rows(tmp_path):
         np.testing.assert_allclose(b.t[n].cpu().numpy(), want[n], rtol=1e-5, atol=1e-7, err_msg=n)
 
 
+def test_restore_on_a_non_default_stream_with_a_smaller_step_counter():
+    """the lazy-Adam bookkeeping reset of bprx_tables_dirty / bprx_set_adam_step is ordered on the CALLER's stream
+    (it used to run on the NULL stream, unordered with respect to the sync / copies a restore had just enqueued on a
+    non-blocking stream): a restore to an EARLIER step inside torch.cuda.stream(s) must not leave last[row] > adam_t."""
+    import torch
+    from fashionvisualexpl_recommend_amd.engine import Engine
+    U, I, k, B = 300, 400, 16, 64
+    t = _tables(U, I, k, 0, 0, seed=11)
+    e = Engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="adam_tf23", lr=0.01, reg=1e-3, max_batch=B).bind(**t)
+    rs = np.random.RandomState(4)
+    bs = [tuple(rs.randint(n, size=B).astype(np.int32) for n in (U, I, I)) for _ in range(10)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for u, i, j in bs[:3]:
+            e.step(_dev(u), _dev(i), _dev(j), want_loss=False)
+        snap = {n: v.clone() for n, v in e.t.items()}
+        step = e.adam_step
+        for u, i, j in bs[3:8]:
+            e.step(_dev(u), _dev(i), _dev(j), want_loss=False)
+        want = None
+        for n, v in snap.items():                                     # restore the EARLIER state (step 3 < 8)
+            e._t[n].copy_(v)
+        e.adam_step = step
+        e.tables_dirty()
+        for u, i, j in bs[3:8]:                                       # the same five steps again
+            e.step(_dev(u), _dev(i), _dev(j), want_loss=False)
+        got = {n: v.cpu().numpy().copy() for n, v in e.t.items()}
+    side.synchronize()
+    o = orc.OracleModel(**t)
+    for u, i, j in bs[:8]:
+        o.step(u, i, j, "adam_tf23", 0.01, 1e-3)
+    for n in ("Gu", "Gi", "Bi"):
+        np.testing.assert_allclose(got[n].reshape(-1), getattr(o, n).reshape(-1), rtol=2e-4, atol=2e-5, err_msg=n)
+
+
+def test_model_attributes_are_current_under_lazy_adam(tmp_path):
+    """model.Gu / .Gi / .Bi (the reference's attribute surface) go through engine.t, i.e. rows that lazy
+    adam_tf23 has not replayed yet are brought up to date before they are handed out."""
+    from argparse import Namespace
+    from fashionvisualexpl_recommend_amd import configs, synth
+    from fashionvisualexpl_recommend_amd.dataset import DataLoader
+    from fashionvisualexpl_recommend_amd.models import BPRMF
+    tr, va, te = synth.make_interactions_clustered(200, 300, per_user=12, clusters=6, p_in=0.9, seed=3)
+    synth.write_dataset(str(tmp_path), "attr", tr, va, te, 300)
+    configs.set_roots(str(tmp_path), str(tmp_path / "results"))
+    params = Namespace(dataset="attr", validation=True, batch_size=64, epochs=1, batch_eval=128, embed_k=16, lr=0.01, reg=1e-3,
+                       top_k=10, verbose=-1, restore_epochs=1, rec="bprmf", best_metric="ndcg", optimizer="adam_tf23", init_seed=0)
+    model = BPRMF(DataLoader(params), params)
+    assert model.engine.adam_is_lazy()                                # (conftest sets BPRX_ADAM_LAZY=1)
+    o = orc.OracleModel(**{n: v.cpu().numpy().copy() for n, v in model.engine.params().items()})
+    rs = np.random.RandomState(8)
+    for _ in range(6):
+        u, i, j = (rs.randint(n, size=64).astype(np.int32) for n in (200, 300, 300))
+        model.train_step((u, i, j))
+        o.step(u, i, j, "adam_tf23", 0.01, 1e-3)
+    for n in ("Gu", "Gi", "Bi"):                                      # most rows were NOT in the last batch: they need the replay
+        np.testing.assert_allclose(getattr(model, n).cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rtol=2e-4, atol=2e-5,
+                                   err_msg=n)
+
+
 def test_adam_policy_picks_sweeps_for_small_batches_and_lazy_for_large_ones(monkeypatch):
     """bprx_create chooses the form from 20 U / B replayed steps against the bytes of a sweep: the reference's own defaults
     (batch 256 on small tables) get sweeps, bench-sized batches the lazy replay; either way the step is the same step

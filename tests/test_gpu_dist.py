@@ -163,6 +163,8 @@ def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather
             for r in range(world):
                 br = np.random.RandomState(300 + step * world + r)
                 nb = B - 10 * r                           # ragged
+                if step == 1 and r == 1:
+                    nb = 0                                 # a rank without local positives: EMPTY batch, every collective joined
                 batches.append((br.randint(U, size=nb).astype(np.int32), br.randint(ish, size=nb).astype(np.int32),
                                 br.randint(ish, size=nb).astype(np.int32)))
             if opt != "sgd" and step >= 2:                # adam: some users only in the OTHER rank's batch, some in nobody's
@@ -286,16 +288,17 @@ def test_replicated_user_message_overflow_is_reported():
     assert ei.value.code == _ffi.E_RANGE
 
 
-def _worker_cli(rank, world, port, root):
+def _worker_cli(rank, world, port, root, dataset, epochs, check_quality):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), BPRX_ONE_GPU="1")
     from fashionvisualexpl_recommend_amd import train_rec
-    out = train_rec.train(["--dataset", "shd", "--rec", "vbpr", "--world_size", str(world), "--shard", "item",
-                           "--dist_backend", "gloo", "--batch_size", "128", "--epochs", "6", "--embed_k", "16", "--embed_d", "8",
-                           "--lr", "0.02", "--top_k", "10", "--optimizer", "adam_tf23", "--dtype", "bf16",
+    out = train_rec.train(["--dataset", dataset, "--rec", "vbpr", "--world_size", str(world), "--shard", "item",
+                           "--dist_backend", "gloo", "--batch_size", "128", "--epochs", str(epochs), "--embed_k", "16", "--embed_d", "8",
+                           "--lr", "0.02", "--top_k", "10", "--optimizer", "adam_tf23", "--dtype", "bf16", "--verbose", "2",
                            "--data_root", root, "--results_root", os.path.join(root, "res")])
     try:
         from fashionvisualexpl_recommend_amd import train_rec as tr
+        from fashionvisualexpl_recommend_amd.evaluator import _eval_block
         m = tr._last_model
         # every replicated table BIT-identical across the ranks
         for n in ("Gu", "Tu", "E", "Bp"):
@@ -303,25 +306,74 @@ def _worker_cli(rank, world, port, root):
             parts = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
             assert all(torch.equal(parts[0], x) for x in parts), n
+        # the shard-additive device metrics == the reference's definitions on the gathered score rows (host evaluator)
+        got = m.metrics(10)
+        sc = m.predict_block(0, m.num_users)
+        full = m.full_state()
         if rank == 0:
+            for key, lst in (("_t", m.data.test_list), ("_v", m.data.validation_list)):
+                rows = np.array(_eval_block(sc, 0, m.data.training_list, lst, 10))
+                for q, name in enumerate(("hr", "p", "r", "auc", "ndcg")):
+                    assert got[name + key] == pytest.approx(rows[:, q].mean(), abs=1e-12), name + key
             res = out[0]
-            assert sorted(res.keys()) == [1, 2, 3, 4, 5, 6]
-            assert res[6]["hr_t"] > 3 * 10 / 240                   # well above a random ranking of the ~240 candidates
-            assert res[6]["ndcg_t"] > res[1]["ndcg_t"] * 0.9
+            assert sorted(res.keys()) == list(range(1, epochs + 1))
+            assert res[epochs]["hr_t"] == pytest.approx(got["hr_t"], abs=1e-12)
+            assert res[epochs]["auc_t"] == res[epochs]["auc_v"]        # the reference's key aliasing (Evaluator.py:220)
+            if check_quality:
+                assert res[epochs]["hr_t"] > 3 * 10 / 240              # well above a random ranking of the ~240 candidates
+                assert res[epochs]["ndcg_t"] > res[1]["ndcg_t"] * 0.9
+            # the reference's output files, written by rank 0 (BPRMF.py:158-183)
+            dp = m.directory_parameters
+            rdir, wdir = os.path.join(root, "res", "rec_results", dataset, "vbpr"), os.path.join(root, "res", "rec_model_weights", dataset, "vbpr")
+            files = os.listdir(rdir) + os.listdir(wdir)
+            assert f"recs-{epochs}-{dp}.tsv" in files and f"results-metrics-{dp}.pkl" in files, files
+            assert any(f.startswith("best-recs-") for f in files) and any(f.startswith("best-weights-") for f in files), files
+            assert f"weights-1-{dp}.pt" in files and f"weights-2-{dp}.pt" in files, files
+            import pickle
+            assert pickle.load(open(os.path.join(rdir, f"results-metrics-{dp}.pkl"), "rb")) == res
+            lines = open(os.path.join(rdir, f"recs-{epochs}-{dp}.tsv")).read().splitlines()
+            assert len(lines) == m.num_users * 10 and lines[0].split("\t")[0] == "0"
+            w = torch.load(os.path.join(wdir, f"weights-2-{dp}.pt"), weights_only=True)
+            assert w["Gi"].shape == (m.num_items, 16) and w["Gu"].shape == (m.num_users, 16) and full["Gi"].shape == w["Gi"].shape
+        return_shard = m.engine.t["Gi"].cpu().numpy()
+        if dataset == "half" and rank == 1:
+            # this rank's shard holds no training positive: empty batches, yet every collective was joined; its item rows
+            # received no gradient (Adam with m = v = 0 leaves a row where it is)
+            rs = np.random.RandomState(0)
+            from fashionvisualexpl_recommend_amd.synth import glorot_uniform
+            glorot_uniform(rs, m.num_users, 16)
+            Gi0 = glorot_uniform(rs, m.num_items, 16)[m.lo:m.hi]
+            assert m.local_pos == 0 and m.sampler is None
+            np.testing.assert_array_equal(return_shard, Gi0)
     finally:
         dist.destroy_process_group()
 
 
 def test_train_rec_cli_item_sharded_two_ranks(tmp_path):
     """train_rec.py --world_size 2 --shard item: sharded feature ingestion, GPU-local negatives, the reference's optimizer
-    through the replicated-user step; two ranks on one GPU (gloo)."""
+    through the replicated-user step, device-side shard-additive evaluation, the reference's output files; two ranks on one
+    GPU (gloo)."""
     from fashionvisualexpl_recommend_amd import synth
     tr, va, te = synth.make_interactions_clustered(300, 240, per_user=22, clusters=12, seed=5)
     F = synth.make_features(240, 128, seed=5)
     cl = np.random.RandomState(5).randint(12, size=240)           # (same seed as the generator's item clusters)
     F += 0.5 * np.eye(12, 128, dtype=np.float32)[cl] * 3          # features that carry the cluster: VBPR can use them
     synth.write_dataset(str(tmp_path), "shd", tr, va, te, 240, features=F.astype(np.float64))
-    mp.spawn(_worker_cli, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_cli, args=(2, _free_port(), str(tmp_path), "shd", 6, True), nprocs=2, join=True)
+
+
+def test_train_rec_cli_rank_without_local_positives(tmp_path):
+    """One item shard holds no training positive: that rank steps with EMPTY batches (count-0 message, zero dense
+    gradient) and still joins every collective -- no deadlock, replicas bit-identical, its item rows untouched."""
+    from fashionvisualexpl_recommend_amd import synth
+    rs = np.random.RandomState(9)
+    U, I = 120, 240
+    tr = [sorted(rs.choice(I // 2, size=12, replace=False).tolist()) for _ in range(U)]     # positives in the lower half only
+    va = [[int(I // 2 + rs.randint(I // 2))] for _ in range(U)]                              # held-out items in the upper half
+    te = [[int(rs.choice([x for x in range(I // 2) if x not in tr[u]]))] for u in range(U)]
+    F = synth.make_features(I, 128, seed=9)
+    synth.write_dataset(str(tmp_path), "half", tr, va, te, I, features=F.astype(np.float64))
+    mp.spawn(_worker_cli, args=(2, _free_port(), str(tmp_path), "half", 2, False), nprocs=2, join=True)
 
 
 def _worker_nosync(rank, world, port):

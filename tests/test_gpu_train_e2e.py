@@ -140,3 +140,17 @@ def test_train_rec_cli_surface_writes_the_reference_outputs(tmp_path):
         assert set(m[2]) == {"hr_v", "auc_v", "p_v", "r_v", "ndcg_v", "hr_t", "auc_t", "p_t", "r_t", "ndcg_t"}
         rows = open(os.path.join(rdir, "recs-2-%s.tsv" % tag)).read().strip().split("\n")
         assert len(rows) == U * 5 and len(rows[0].split("\t")) == 3
+
+
+def test_cli_sampler_philox_trains_on_the_device_epoch_walk(tmp_path):
+    """`--sampler philox` with one GPU now drives BPRMF.train from the device epoch-walk sampler (it used to be
+    parsed and ignored).  Same epoch accounting as the reference's stream; the model learns."""
+    from fashionvisualexpl_recommend_amd import train_rec
+    tr, va, te = synth.make_interactions_clustered(300, 500, per_user=14, clusters=10, p_in=0.9, seed=7)
+    synth.write_dataset(str(tmp_path), "phx", tr, va, te, 500)
+    out = train_rec.train(["--dataset", "phx", "--rec", "bprmf", "--batch_size", "128", "--epochs", "4", "--embed_k", "16",
+                           "--lr", "0.01", "--top_k", "10", "--sampler", "philox", "--data_root", str(tmp_path),
+                           "--results_root", str(tmp_path / "res")])
+    res = out[0]
+    assert sorted(res) == [1, 2, 3, 4]
+    assert res[4]["hr_t"] > 2 * 10 / 500 and res[4]["ndcg_t"] >= res[1]["ndcg_t"] * 0.9
