@@ -33,7 +33,11 @@ WORKLOADS = {
     # BASELINE.json configs[3] per-GPU shard shape (VBPR k=128, 2M x 500K over 8 GPUs -> 250K users, 62.5K items/GPU)
     "c4shard": dict(model="vbpr", U=250_000, I=62_500, k=128, d=128, D=4096, dtype="bf16", B=65_536),
     # BASELINE.json configs[4]: VBPR k = d = 256, fp8 (e4m3fn) feature table resident in HBM; and its bf16 twin
-    "c5": dict(model="vbpr", U=100_000, I=50_000, k=256, d=256, D=4096, dtype="fp8", B=65_536),
+    # (HBM scale, SURVEY 8 sizing "I = 500 K -> 2 GB": the table is 8x the 256-MiB Infinity Cache; B = 2^18 so that 2B >= I and
+    #  the step streams the whole table like C2 does -- at B = 65 536 the library's per-step policy takes the touched-item list)
+    "c5": dict(model="vbpr", U=1_000_000, I=500_000, k=256, d=256, D=4096, dtype="fp8", B=262_144),
+    "c5list": dict(model="vbpr", U=1_000_000, I=500_000, k=256, d=256, D=4096, dtype="fp8", B=65_536),
+    "c5small": dict(model="vbpr", U=100_000, I=50_000, k=256, d=256, D=4096, dtype="fp8", B=65_536),   # fits the Infinity Cache
     "c5bf16": dict(model="vbpr", U=100_000, I=50_000, k=256, d=256, D=4096, dtype="bf16", B=65_536),
     # configs[1] shape with fp8 features (what the fp8 table buys on the headline shape)
     "c2fp8": dict(model="vbpr", U=100_000, I=50_000, k=64, d=64, D=4096, dtype="fp8", B=65_536),

@@ -83,10 +83,16 @@ def lib():
         "bprx_step_end": (C.c_int, [vp, vp, vp]),
         "bprx_step_project": (C.c_int, [vp, vp]),
         "bprx_user_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
-        "bprx_clear_user_grad": (C.c_int, [vp, i64, vp]),
+        "bprx_clear_user_grad": (C.c_int, [vp, i64, i32, vp]),
         "bprx_item_grad": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
-        "bprx_clear_item_grad": (C.c_int, [vp, i64, vp]),
+        "bprx_clear_item_grad": (C.c_int, [vp, i64, i32, vp]),
         "bprx_scatter_add": (C.c_int, [vp, i32, i32, vp, vp, i64, f32, vp]),
+        "bprx_route_reset": (C.c_int, [vp, i64, vp, i32, vp]),
+        "bprx_route_plan": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "bprx_route_gather": (C.c_int, [vp, i32, vp, i32, i32, vp, i64, vp, vp]),
+        "bprx_route_unpack": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, i32, vp]),
+        "bprx_route_pack": (C.c_int, [vp, i32, vp, i32, vp, i64, vp, vp, vp, i32, f32, vp]),
+        "bprx_route_scatter_add": (C.c_int, [vp, i32, vp, i32, i32, vp, vp, i64, f32, vp]),
         "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
         "bprx_eval_users": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
         "bprx_topk": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
@@ -123,7 +129,8 @@ EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_adam_is_lazy", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
-           "bprx_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_eval_pos", "bprx_eval_counts", "bprx_eval_finish", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
+           "bprx_scatter_add", "bprx_route_reset", "bprx_route_plan", "bprx_route_gather", "bprx_route_unpack", "bprx_route_pack",
+           "bprx_route_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_eval_pos", "bprx_eval_counts", "bprx_eval_finish", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
            "bprx_profile_read", "bprx_sample_philox", "bprx_sample_epoch", "bprx_user_msg_floats", "bprx_pack_user_msg",
            "bprx_apply_user_msgs", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]

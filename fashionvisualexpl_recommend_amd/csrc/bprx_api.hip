@@ -527,11 +527,13 @@ extern "C" int bprx_user_grad(bprx_handle *h, float **dGu, float **dTu) {
   return BPRX_OK;
 }
 
-extern "C" int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream) {
+extern "C" int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, int32_t marks_only, void *stream) {
   if (!h || n_rows < 0 || n_rows > h->cfg.num_users) return BPRX_E_INVALID;
   hipStream_t s = (hipStream_t)stream;
-  BPRX_HIP(h, hipMemsetAsync(h->dGu, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
-  if (h->cfg.embed_d) BPRX_HIP(h, hipMemsetAsync(h->dTu, 0, (size_t)n_rows * h->cfg.embed_d * sizeof(float), s));
+  if (!marks_only) {                                       // (bprx_route_pack has already returned the gradient rows to zero)
+    BPRX_HIP(h, hipMemsetAsync(h->dGu, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
+    if (h->cfg.embed_d) BPRX_HIP(h, hipMemsetAsync(h->dTu, 0, (size_t)n_rows * h->cfg.embed_d * sizeof(float), s));
+  }
   BPRX_HIP(h, hipMemsetAsync(h->flagU, 0, (size_t)n_rows * sizeof(uint32_t), s));
   return BPRX_OK;
 }
@@ -543,11 +545,13 @@ extern "C" int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi) {
   return BPRX_OK;
 }
 
-extern "C" int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, void *stream) {
+extern "C" int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, int32_t marks_only, void *stream) {
   if (!h || n_rows < 0 || n_rows > h->cfg.num_items) return BPRX_E_INVALID;
   hipStream_t s = (hipStream_t)stream;
-  BPRX_HIP(h, hipMemsetAsync(h->dGi, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
-  BPRX_HIP(h, hipMemsetAsync(h->dBi, 0, (size_t)n_rows * sizeof(float), s));
+  if (!marks_only) {
+    BPRX_HIP(h, hipMemsetAsync(h->dGi, 0, (size_t)n_rows * h->cfg.embed_k * sizeof(float), s));
+    BPRX_HIP(h, hipMemsetAsync(h->dBi, 0, (size_t)n_rows * sizeof(float), s));
+  }
   BPRX_HIP(h, hipMemsetAsync(h->flagI, 0, (size_t)n_rows * sizeof(uint32_t), s));
   return BPRX_OK;
 }

@@ -224,10 +224,17 @@ class Engine:
         return self._igrad
 
     def clear_item_grad(self, n_rows):
-        _ffi.check(self.h, self.lib.bprx_clear_item_grad(self.h, int(n_rows), _stream()))
+        _ffi.check(self.h, self.lib.bprx_clear_item_grad(self.h, int(n_rows), 0, _stream()))
 
     def clear_user_grad(self, n_rows):
-        _ffi.check(self.h, self.lib.bprx_clear_user_grad(self.h, int(n_rows), _stream()))
+        _ffi.check(self.h, self.lib.bprx_clear_user_grad(self.h, int(n_rows), 0, _stream()))
+
+    def clear_item_marks(self, n_rows):
+        """After bprx_route_pack (which returns the exported gradient rows to zero): only the touched-row marks are left."""
+        _ffi.check(self.h, self.lib.bprx_clear_item_grad(self.h, int(n_rows), 1, _stream()))
+
+    def clear_user_marks(self, n_rows):
+        _ffi.check(self.h, self.lib.bprx_clear_user_grad(self.h, int(n_rows), 1, _stream()))
 
     def step_end(self, want_loss=True, loss_out=None, loss_index=0):
         """loss_out / loss_index: as in step() -- the loss lands in element `loss_index` of a device tensor."""

@@ -84,9 +84,11 @@ def train(argv=None):
         if world > 1 and args.rec == 'vbpr' and args.shard == 'item':
             from .sharded import ShardedVBPR
             model = ShardedVBPR(data, args)
+        elif world > 1 and args.rec == 'bprmf' and args.shard == 'user':
+            from .sharded import ShardedBPRMF
+            model = ShardedBPRMF(data, args)
         elif world > 1:
-            raise NotImplementedError('--world_size > 1 from this CLI: --rec vbpr --shard item (user-sharded BPRMF is driven '
-                                      'through dist.UserShardedBPRMF / bench.py --workload c3shard)')
+            raise NotImplementedError('--world_size > 1 from this CLI: --rec vbpr --shard item, or --rec bprmf --shard user')
         elif args.rec == 'bprmf':
             model = BPRMF(data, args)
         elif args.rec == 'vbpr':

@@ -171,7 +171,8 @@ BPRX_API int bprx_step_begin_dense(bprx_handle *h, void *stream);
    the owner-side application of routed gradient rows.  Stateless; all pointers are device pointers. */
 BPRX_API int bprx_step_project(bprx_handle *h, void *stream);
 BPRX_API int bprx_user_grad(bprx_handle *h, float **dGu, float **dTu);
-BPRX_API int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, void *stream);
+BPRX_API int bprx_clear_user_grad(bprx_handle *h, int64_t n_rows, int32_t marks_only, void *stream);   /* marks_only: the gradient
+   rows were already returned to zero (bprx_route_pack); only the touched-row marks are cleared */
 /* Replicated-user multi-GPU step (item-sharded VBPR with every rank holding ALL user rows; needs
    BPRX_FLAG_EXPORT_USER_GRAD and a handle created with num_users = the GLOBAL user count): ONE fixed-size all-gather per
    step, no data-dependent routing, no host synchronisation.
@@ -195,9 +196,40 @@ BPRX_API int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, 
 BPRX_API int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t nranks, int64_t cap, float scale, void *stream);
 BPRX_API int bprx_sum_dense_parts(bprx_handle *h, const float *parts, int32_t nranks, void *stream);
 BPRX_API int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi);
-BPRX_API int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, void *stream);
+BPRX_API int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, int32_t marks_only, void *stream);
 BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,
                               int64_t n, float scale, void *stream);
+
+/* Fixed-capacity row routing for the all-to-all multi-GPU modes (user-sharded BPRMF moves item rows, the
+   partitioned-user form of item-sharded VBPR moves user rows).  Stateless, device pointers only.  Every rank sends exactly `cap`
+   slots to every rank: the collectives take equal splits and nothing is read back to the host to size them.  A routed row is
+   [w0 floats | w1 floats | pad] with a stride of (w0 + w1 + 3) & ~3 floats (buffers of nranks*cap such rows).  Per step:
+     requester  bprx_route_reset(send_idx, nranks*cap, cursor, nranks)   send_idx <- -1 (unused slot), cursors <- 0
+                bprx_route_plan(ids[n] global row ids, rows_per_rank = rows of a full shard, ...) -> slot[n] (owner*cap + position,
+                  -1 and *overflow = 1 when the owner's bucket is full or the id is out of range), send_idx[slot] = owner-local row id
+                all-to-all(send_idx) -> recv_idx: the rows the other ranks ask this rank for
+     owner      bprx_route_gather(t0, w0, t1, w1, num_rows, recv_idx, nranks*cap, out): out[q] = [t0[idx] | t1[idx]] (w1 = 0: one table)
+                all-to-all(out) -> got
+     requester  bprx_route_unpack(got, slot, n, dst0, w0, dst1, w1): row r of the staging tables = got[slot[r]] (zero row for -1)
+                ... local step (BPRX_FLAG_EXPORT_*_GRAD) ...
+                bprx_route_pack(grad0, w0, grad1, w1, slot, n, send): send[slot[r]] = [grad0[r] | grad1[r]]; the gradient rows are
+                  returned to zero (replaces bprx_clear_*_grad); all-to-all(send) -> back, aligned with recv_idx
+     owner      bprx_route_scatter_add(t0, w0, t1, w1, num_rows, recv_idx, back, nranks*cap, scale): t[idx] += scale * row
+                  (fp32 atomics, duplicates summed; unused slots skipped).
+   Rows the requesting rank owns itself (my_rank; -1: none) never enter the send buffers: bprx_route_plan gives them slot
+   -2 - local row id, bprx_route_unpack copies them from own0 / own1 (the rank's shard tables, own_rows rows) and bprx_route_pack
+   adds scale * gradient into own0 / own1 directly. */
+BPRX_API int bprx_route_reset(int32_t *send_idx, int64_t nslots, int32_t *cursor, int32_t nranks, void *stream);
+BPRX_API int bprx_route_plan(const int32_t *ids, int64_t n, int32_t rows_per_rank, int32_t nranks, int32_t cap, int32_t my_rank,
+                             int32_t *slot, int32_t *send_idx, int32_t *cursor, int32_t *overflow, void *stream);
+BPRX_API int bprx_route_gather(const float *t0, int32_t w0, const float *t1, int32_t w1, int32_t num_rows, const int32_t *idx,
+                               int64_t n, float *out, void *stream);
+BPRX_API int bprx_route_unpack(const float *got, const int32_t *slot, int64_t n, float *dst0, int32_t w0, float *dst1, int32_t w1,
+                               const float *own0, const float *own1, int32_t own_rows, void *stream);
+BPRX_API int bprx_route_pack(float *src0, int32_t w0, float *src1, int32_t w1, const int32_t *slot, int64_t n, float *send,
+                             float *own0, float *own1, int32_t own_rows, float scale, void *stream);
+BPRX_API int bprx_route_scatter_add(float *t0, int32_t w0, float *t1, int32_t w1, int32_t num_rows, const int32_t *idx,
+                                    const float *rows, int64_t n, float scale, void *stream);
 
 /* Model.predict_all() rows [u0,u1)   BPRMF.py:78-85 / VBPR.py:88-97.   out: fp32 [(u1-u0), I] */
 BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream);

@@ -24,3 +24,9 @@ if l:
     d=json.loads(l); d['bench_args']='$spec'; print(json.dumps(d))" >> $O/bench_others.jsonl
   echo "-- $spec"; summ $O/tmp.log
 done
+if [ "${FORCED:-0}" = "1" ]; then
+  echo "== forced sharded N=1 (RCCL world 1)"
+  BPRX_BENCH_FORCE_SHARDED=1 t 300 python bench.py --no-cpu-baseline > $O/tmp.log 2>&1; grep '^{"metric"' $O/tmp.log | tail -1 > $O/bench_c2_forced_sharded_n1.json; summ $O/tmp.log
+  BPRX_BENCH_FORCE_SHARDED=1 t 300 python bench.py --no-cpu-baseline --optimizer adam_tf23 > $O/tmp.log 2>&1; grep '^{"metric"' $O/tmp.log | tail -1 > $O/bench_c2_forced_sharded_n1_adam.json; summ $O/tmp.log
+  BPRX_BENCH_FORCE_SHARDED=1 t 300 python bench.py --no-cpu-baseline --workload c3shard > $O/tmp.log 2>&1; grep '^{"metric"' $O/tmp.log | tail -1 > $O/bench_c3shard_forced_sharded_n1.json; summ $O/tmp.log
+fi

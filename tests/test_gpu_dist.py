@@ -376,6 +376,59 @@ def test_train_rec_cli_rank_without_local_positives(tmp_path):
     mp.spawn(_worker_cli, args=(2, _free_port(), str(tmp_path), "half", 2, False), nprocs=2, join=True)
 
 
+def _worker_cli_user(rank, world, port, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), BPRX_ONE_GPU="1")
+    from fashionvisualexpl_recommend_amd import train_rec
+    epochs = 8
+    out = train_rec.train(["--dataset", "ush", "--rec", "bprmf", "--world_size", str(world), "--shard", "user",
+                           "--dist_backend", "gloo", "--batch_size", "128", "--epochs", str(epochs), "--embed_k", "16",
+                           "--lr", "0.15", "--top_k", "10", "--optimizer", "sgd", "--verbose", "2",
+                           "--data_root", root, "--results_root", os.path.join(root, "res")])
+    try:
+        from argparse import Namespace
+        from fashionvisualexpl_recommend_amd import train_rec as tr
+        m = tr._last_model
+        got = m.metrics(10)
+        full = m.full_state()
+        if rank == 0:
+            # the same tables in a single-GPU model: its device evaluator must give the same means (same score kernel)
+            from fashionvisualexpl_recommend_amd.models import BPRMF
+            params = Namespace(dataset="ush", validation=True, batch_size=128, epochs=1, batch_eval=128, embed_k=16, lr=0.05, reg=0.0,
+                               top_k=10, verbose=-1, restore_epochs=1, rec="bprmf", best_metric="ndcg", optimizer="sgd", init_seed=0)
+            single = BPRMF(m.data, params, init={n: full[n].numpy() for n in ("Gu", "Gi", "Bi")})
+            want = single.evaluator.metrics()
+            for key in want:
+                assert got[key] == pytest.approx(want[key], abs=1e-12), key
+            res = out[0]
+            assert sorted(res.keys()) == list(range(1, epochs + 1))
+            assert res[epochs]["hr_t"] == pytest.approx(got["hr_t"], abs=1e-12)
+            print("AUC/HR per epoch", [(round(res[e]["auc_v"], 4), round(res[e]["hr_t"], 4)) for e in sorted(res)])
+            assert res[epochs]["auc_v"] > res[1]["auc_v"] + 0.01 and res[epochs]["hr_t"] > 2.5 * 10 / 240      # it learns
+            dp = m.directory_parameters
+            rdir, wdir = os.path.join(root, "res", "rec_results", "ush", "bprmf"), os.path.join(root, "res", "rec_model_weights", "ush", "bprmf")
+            files = os.listdir(rdir) + os.listdir(wdir)
+            assert f"recs-{epochs}-{dp}.tsv" in files and f"results-metrics-{dp}.pkl" in files, files
+            assert any(f.startswith("best-recs-") for f in files) and any(f.startswith("best-weights-") for f in files), files
+            lines = open(os.path.join(rdir, f"recs-{epochs}-{dp}.tsv")).read().splitlines()
+            assert len(lines) == m.num_users * 10 and [l.split("\t")[0] for l in lines[::10]] == [str(u) for u in range(m.num_users)]
+            # ... and the single-GPU evaluator writes the same file from the same tables
+            p1 = os.path.join(root, "single.tsv")
+            single.evaluator.store_recommendation(p1)
+            assert open(p1).read() == open(os.path.join(rdir, f"recs-{epochs}-{dp}.tsv")).read()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_rec_cli_user_sharded_two_ranks(tmp_path):
+    """train_rec.py --world_size 2 --shard user --rec bprmf: user rows stay on their rank, item rows travel by the fixed-capacity
+    all-to-alls (routing in HIP kernels), every rank evaluates its own users on the device; the reference's outputs from rank 0."""
+    from fashionvisualexpl_recommend_amd import synth
+    tr, va, te = synth.make_interactions_clustered(301, 240, per_user=22, clusters=12, seed=5)      # 301: unequal user shards
+    synth.write_dataset(str(tmp_path), "ush", tr, va, te, 240)
+    mp.spawn(_worker_cli_user, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
 def _worker_nosync(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
