@@ -1269,13 +1269,22 @@ __global__ __launch_bounds__(512) void k_proj_fwd_bf16_v10(const uint16_t *__res
 //   * two-stage pipeline, one barrier per chunk: chunk c+1's feature fragments and B pieces are requested before chunk
 //     c's MFMAs (scheduling fences keep hipcc from sinking them), the B pieces are parked in the other LDS buffer after.
 // Balanced share of the row tiles per workgroup as in v8; the body is instantiated for 1 and 2 row tiles and picked per wave.
+//   * (round 3) WHOLE-LINE feature loads: a 16-row tile x 128-k chunk is 16 aligned 128-B lines of the tiled F (rows 256 B
+//     apart); a load instruction takes 8 of them whole (lane l: row 8x + l/8, 16-B piece l%8) instead of half of all 16 (the
+//     operand-order fragment loads of round 2 asked for every line twice, 64 B each time).  The pieces pass through a
+//     WAVE-PRIVATE 2-KB LDS image per tile (piece p of row i at i*128 + ((p ^ (i&7) ^ (i>>3)) * 16): conflict-free for the
+//     8-lane store groups and the 16-lane read groups alike) and come back in MFMA operand order into the same registers:
+//     two ds_write_b128 + two ds_read_b128 per tile and chunk, no barrier.  NTL: the loads carry `nt` -- for tables larger
+//     than the Infinity Cache (configs[4] at I = 500 K: 2 GB), which a pass must stream without evicting P and the factors;
+//     a table that fits the cache (I = 50 K: 205 MB) keeps default-policy loads, the backward pass re-reads it from there.
 // ------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
-template <int NT, int MT>
-__device__ __forceinline__ void f8s_body(const unsigned char *const (&arow)[2], const unsigned char *__restrict__ EtS,
-                                         unsigned char *lds, int nch, int cshift, int lane, float *__restrict__ P, int PS,
-                                         int nrows, int first, int nstore, float ps) {
+template <int NT, int MT, bool NTL>
+__device__ __forceinline__ void f8s_body(const unsigned char *const (&arow)[2][2], const unsigned char *__restrict__ EtS,
+                                         unsigned char *lds, unsigned char *myA, int nch, int cshift, int lane,
+                                         float *__restrict__ P, int PS, int nrows, int first, int nstore, float ps,
+                                         const int32_t *__restrict__ rows, int scatter, int nitems) {
   constexpr int BCH = NT * 2048;                        // bytes of one [E|Bp]^T chunk
   constexpr int NPIECE = NT * 128;                      // its 16-B pieces
   constexpr int NBP = (NPIECE + 511) / 512;             // pieces per thread (the last round clamps onto the last piece)
@@ -1286,16 +1295,22 @@ __device__ __forceinline__ void f8s_body(const unsigned char *const (&arow)[2], 
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x8_t aX[MT], aY[MT];                               // 32 B per lane and row tile: one scaled-MFMA A operand
+  i32x8_t aX[MT], aY[MT];                               // 32 B per lane and row tile: first the loaded pieces, then the operand
   i32x4_t bst[NBP];
+  // wave-private image: store position of (my loaded) piece l%8 of rows l/8 and 8 + l/8; read position of operand pieces 2g, 2g+1
+  const int i_w = lane >> 3, p_w = lane & 7, i_r = lane & 15, g_r = lane >> 4;
+  const int wo0 = i_w * 128 + ((p_w ^ (i_w & 7)) << 4);                               // row i_w       (i >> 3 == 0)
+  const int wo1 = (8 + i_w) * 128 + ((p_w ^ (i_w & 7) ^ 1) << 4);                     // row 8 + i_w   (i >> 3 == 1)
+  const int sw_r = (i_r & 7) ^ (i_r >> 3);
+  const int ro0 = i_r * 128 + (((2 * g_r) ^ sw_r) << 4), ro1 = i_r * 128 + (((2 * g_r + 1) ^ sw_r) << 4);
 #define F8S_ISSUE(c_, AR)                                                                                             \
   {                                                                                                                   \
     int ce_ = (c_) + cshift;                                                                                          \
     if (ce_ >= nch) ce_ -= nch;                                                                                       \
     const size_t ao_ = (size_t)(ce_ >> 1) * 8192 + (size_t)(ce_ & 1) * 128;                                           \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                               \
-      AR[mt].lo = *reinterpret_cast<const i32x4_t *>(arow[mt] + ao_);                                                 \
-      AR[mt].hi = *reinterpret_cast<const i32x4_t *>(arow[mt] + ao_ + 16);                                            \
+      AR[mt].lo = ld_stream16<NTL>(arow[mt][0] + ao_);                                                                \
+      AR[mt].hi = ld_stream16<NTL>(arow[mt][1] + ao_);                                                                \
     }                                                                                                                 \
     const unsigned char *bc_ = EtS + (size_t)ce_ * BCH;                                                               \
     _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                 \
@@ -1314,6 +1329,16 @@ __device__ __forceinline__ void f8s_body(const unsigned char *const (&arow)[2], 
   }
 #define F8S_COMPUTE(buf_, AR)                                                                                         \
   {                                                                                                                   \
+    /* loaded pieces -> wave-private image -> operand order, in the same registers (LDS operations of a wave complete \
+       in order: the reads see the stores; the previous chunk's reads have long been consumed) */                      \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                               \
+      *reinterpret_cast<i32x4_t *>(myA + mt * 2048 + wo0) = AR[mt].lo;                                                \
+      *reinterpret_cast<i32x4_t *>(myA + mt * 2048 + wo1) = AR[mt].hi;                                                \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                               \
+      AR[mt].lo = *reinterpret_cast<const i32x4_t *>(myA + mt * 2048 + ro0);                                          \
+      AR[mt].hi = *reinterpret_cast<const i32x4_t *>(myA + mt * 2048 + ro1);                                          \
+    }                                                                                                                 \
     /* fragment nt+1 is read from LDS before the MFMAs of fragment nt; the fences keep hipcc from hoisting ALL NT     \
        fragment reads (8 registers each) above the first MFMA */                                                      \
     const unsigned char *bl_ = lds + (buf_) * BCH + lane * 16;                                                        \
@@ -1359,40 +1384,56 @@ __device__ __forceinline__ void f8s_body(const unsigned char *const (&arow)[2], 
     for (int reg = 0; reg < 4; ++reg) {
       const int t = (first + mt) * 16 + g * 4 + reg;     // C/D layout: col = lane & 15, row = (lane >> 4)*4 + reg
       if (t < nrows) {
+        int orow = t;                                     // row list: row t of the result is item rows[t] (scattered to P[item])
+        if (scatter) { orow = rows[t]; orow = (unsigned)orow < (unsigned)nitems ? orow : 0; }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)orow * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
       }
     }
   }
 }
 
-template <int NT>
+template <int NT, bool NTL>
 __global__ __launch_bounds__(512) void k_proj_fwd_f8s(const unsigned char *__restrict__ F, int nrows, int D,
                                                       const unsigned char *__restrict__ EtS, float *__restrict__ P, int PS,
-                                                      const float *__restrict__ pscale, int stagger) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_f8s[];   // 2 x NT*2048
+                                                      const float *__restrict__ pscale, int stagger,
+                                                      const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev,
+                                                      int scatter, int nitems, int32_t *__restrict__ errflag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_f8s[];   // 2 x NT*2048 ([E|Bp]^T chunks) | 8 waves x 2 tiles x 2 KB
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, g = lane >> 4;
+  // rows != nullptr: the projection of the LISTED items (list mode of large batches: a listed item's 256-B pieces are whole
+  // line pairs of the tiled F, so the gather streams like the table does); the list length comes from the device
+  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
+  if (nrows <= 0) return;                                // (workgroup-uniform)
   const int T = (nrows + 15) >> 4;
   const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
   const int ntile = t1 - t0;                             // <= 16: the launcher sizes the grid for it
+  if (ntile == 0) return;                                // (a row list shorter than its host-side bound; workgroup-uniform)
   const int base = ntile >> 3, rem = ntile & 7;
   const int nlive = base + (w < rem ? 1 : 0);            // this wave's row tiles (wave-uniform, 0..2)
   const int first = t0 + w * base + (w < rem ? w : rem);
-  const unsigned char *arow[2];
+  const unsigned char *arow[2][2];                       // [tile][rows 0-7 / rows 8-15]: my 16-B piece of my row's 128-B line
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     int tile = first + mt;
     if (mt >= nlive) tile = nlive ? first + nlive - 1 : (T ? T - 1 : 0);     // never stored
-    int t = tile * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    arow[mt] = F + ((size_t)(t >> 5) * (size_t)(D >> 8)) * 8192 + (size_t)(t & 31) * 256 + g * 32;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      int t = tile * 16 + 8 * x + (lane >> 3);
+      if (t >= nrows) t = nrows - 1;
+      if (rows) {
+        t = rows[t];
+        if ((unsigned)t >= (unsigned)nitems) { *errflag = 2; t = 0; }
+      }
+      arow[mt][x] = F + ((size_t)(t >> 5) * (size_t)(D >> 8)) * 8192 + (size_t)(t & 31) * 256 + (lane & 7) * 16;
+    }
   }
   const int nch = D >> 7;
   const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
   const float ps = *pscale;
-  if (nlive == 2) f8s_body<NT, 2>(arow, EtS, lds_f8s, nch, cshift, lane, P, PS, nrows, first, 2, ps);   // same barrier sequence
-  else f8s_body<NT, 1>(arow, EtS, lds_f8s, nch, cshift, lane, P, PS, nrows, first, nlive, ps);          // 0: a spare wave
+  unsigned char *myA = lds_f8s + 2 * NT * 2048 + w * 4096;
+  if (nlive == 2) f8s_body<NT, 2, NTL>(arow, EtS, lds_f8s, myA, nch, cshift, lane, P, PS, nrows, first, 2, ps, rows, scatter, nitems);
+  else f8s_body<NT, 1, NTL>(arow, EtS, lds_f8s, myA, nch, cshift, lane, P, PS, nrows, first, nlive, ps, rows, scatter, nitems);   // 0: a spare wave
 }
 
 // dEp[k*d + n] = sum_s part[s][k][n] (n < d) ; dEp[D*d + k] = sum_s part[s][k][d]
@@ -1787,6 +1828,32 @@ void launch_fwd_rows(bprx_handle *h, const int32_t *rows, int64_t nrows, const i
 #undef ROWS_LAUNCH
 }
 
+// fp8 features, wide projection (NT >= 10): ONE pass on the block-scaled fp8 MFMA (k_proj_fwd_f8s), over the whole table or a
+// row list (nrows = the host-side bound of the list, the length is read on the device)
+template <int NT>
+void launch_f8s(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_t *nrows_dev, int scatter, float *Pout, hipStream_t s,
+                int stagger) {
+  const float *pscale = h->qs + 1;
+  const int64_t T = (nrows + 15) / 16;
+  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+  int64_t G = (T + 15) / 16;                              // at most 16 row tiles per workgroup (8 waves x 2)
+  if (G < ncu) G = T < ncu ? T : ncu;
+  else G = (G + ncu - 1) / ncu * ncu;
+  const size_t lds = (size_t)2 * NT * 2048 + 8 * 4096;
+  // streaming (`nt`) loads when the table cannot stay in the 256-MiB Infinity Cache between the two passes of a step
+  const bool ntl = (size_t)h->cfg.num_items * h->cfg.feat_dim > ((size_t)192 << 20);
+#define F8S_LAUNCH(NTL_)                                                                                                  \
+  do {                                                                                                                    \
+    auto kfn = k_proj_fwd_f8s<NT, NTL_>;                                                                                  \
+    (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(512), lds, s, (const unsigned char *)h->Ft, (int)nrows, h->cfg.feat_dim,  \
+                       (const unsigned char *)h->EtS, Pout, h->PS, pscale, stagger, rows, nrows_dev, scatter, h->cfg.num_items, \
+                       h->errflag);                                                                                        \
+  } while (0)
+  if (ntl) F8S_LAUNCH(true); else F8S_LAUNCH(false);
+#undef F8S_LAUNCH
+}
+
 template <int NT>
 int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
   constexpr int MTD = NT <= 9 ? 2 : 1;
@@ -1829,16 +1896,7 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
     // column-range passes of v8 for A/B measurements
     const int f8s_on = getenv("BPRX_F8S") ? atoi(getenv("BPRX_F8S")) : 1;
     if (f8 && v == 4 && f8s_on && h->EtS && h->cfg.feat_dim % 256 == 0) {
-      const int64_t T = (nrows + 15) / 16;
-      const int ncu = h->num_cu > 0 ? h->num_cu : 256;
-      int64_t G = (T + 15) / 16;                              // at most 16 row tiles per workgroup (8 waves x 2)
-      if (G < ncu) G = T < ncu ? T : ncu;
-      else G = (G + ncu - 1) / ncu * ncu;
-      const size_t lds = (size_t)2 * NT * 2048;
-      auto kfn = k_proj_fwd_f8s<NT>;
-      (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(512), lds, s, (const unsigned char *)h->Ft, (int)nrows, h->cfg.feat_dim,
-                         (const unsigned char *)h->EtS, Pout, h->PS, pscale, stg & 1);
+      launch_f8s<NT>(h, nullptr, nrows, nullptr, 0, Pout, s, stg & 1);
       return 0;
     }
   }
@@ -2062,6 +2120,23 @@ int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, con
   BprxProfScope ps(h, BPRX_PHASE_PROJ_FWD, s);
   if (h->cfg.feat_dtype != BPRX_F_FP32) {
     const int NT = h->PS / 16;
+    if (rows && NT >= 10 && h->cfg.feat_dtype == BPRX_F_FP8 && h->EtS && h->cfg.feat_dim % 256 == 0 && nrows >= 4096 &&
+        !(getenv("BPRX_F8S") && atoi(getenv("BPRX_F8S")) == 0)) {
+      // a LARGE row list of a wide fp8 projection (list mode at configs[4] scale: ~123 K distinct items per batch of 65 536):
+      // the one-pass streaming kernel gathers the listed rows (k_proj_fwd_rows is built for lists of a few hundred rows)
+      switch (NT) {
+        case 10: launch_f8s<10>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        case 11: launch_f8s<11>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        case 12: launch_f8s<12>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        case 13: launch_f8s<13>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        case 14: launch_f8s<14>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        case 15: launch_f8s<15>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        case 16: launch_f8s<16>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+        default: launch_f8s<17>(h, rows, nrows, nrows_dev, scatter, Pout, s, 0); break;
+      }
+      BPRX_LAUNCH_CHECK(h, "k_proj_fwd_f8s<rows>");
+      return BPRX_OK;
+    }
     if (rows) {                                          // row list: K split over the waves of one workgroup per 16-64 rows
 #define CALL(N) launch_fwd_rows<N>(h, rows, nrows, nrows_dev, scatter, Pout, s)
       NT_SWITCH(NT, CALL)

@@ -1,6 +1,8 @@
 """BASELINE.json configs[1], [3] (per-GPU shard) and [4] at FULL size -- VBPR k=d=64 bf16 100K x 50K; VBPR k=d=128 bf16
 250K x 62.5K (the c4shard shape: the 9-tile forward, the 8-wave backward with three tiles in flight); VBPR k=d=256 fp8
-(17 column tiles, column-range forward passes, fp8 feature table) -- and the configs[2] per-GPU shard (BPRMF k=128,
+(17 column tiles, the one-pass scaled-fp8 forward) at the cache-resident size (c5small: 100K x 50K, 205-MB table), at HBM
+scale (c5: 1M x 500K, a 2-GB table streamed with `nt` loads, B = 262 144) and in list mode at that scale (c5list: B = 65 536,
+the projections run over the batch's distinct items) -- and the configs[2] per-GPU shard (BPRMF k=128,
 625K x 1M): the oracle cannot run these in seconds, so the HIP path is checked through size-independent properties and
 against an independent torch fp32 recomputation of the SAME step on the device with the same operand rounding (torch is
 the checker here, never the product path).  Reference: VBPR.py:59-144, BPRMF.py:55-125."""
@@ -36,7 +38,7 @@ def _sampler_properties(U, I, B, dev, g):
     return u, i, j
 
 
-@pytest.mark.parametrize("workload", ["c2", "c4shard", "c5"])
+@pytest.mark.parametrize("workload", ["c2", "c4shard", "c5small", "c5", "c5list"])
 def test_vbpr_full_size_step_against_torch_fp32(workload):
     from fashionvisualexpl_recommend_amd.engine import Engine
     w, dev, t = _state(workload)
