@@ -69,7 +69,6 @@ def lib():
         "bprx_bind_tables": (C.c_int, [vp, C.POINTER(Tables)]),
         "bprx_set_hyper": (C.c_int, [vp, f32, f32]),
         "bprx_tables_dirty": (C.c_int, [vp, vp]),
-        "bprx_kernel_variant_safe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "bprx_set_adam_step": (C.c_int, [vp, i64, vp]),
         "bprx_get_adam_step": (i64, [vp]),
         "bprx_adam_is_lazy": (C.c_int, [vp]),
@@ -125,7 +124,7 @@ def lib():
     return L
 
 
-EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty", "bprx_kernel_variant_safe",
+EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error", "bprx_bind_tables", "bprx_set_hyper", "bprx_tables_dirty",
            "bprx_set_adam_step", "bprx_get_adam_step", "bprx_adam_is_lazy", "bprx_sync_adam", "bprx_score_pairs", "bprx_step", "bprx_step_begin",
            "bprx_step_begin_sparse", "bprx_step_begin_dense", "bprx_sum_dense_parts",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",

@@ -25,39 +25,6 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _safe_table(remarks):
-    """The software-pipelined forward kernels (k_proj_fwd_bf16_v6 / _v7) keep asm-issued loads in flight across
-    instructions the compiler schedules freely; that is only sound if the compiler never spills or shuffles those
-    registers.  From hipcc's -Rpass-analysis=kernel-resource-usage remarks, list the instantiations that are free of
-    scratch, VGPR spills and AGPR use beyond the MFMA accumulators; the launcher falls back to the plain kernel for
-    every other instantiation.  Returns the C++ source of bprx_variant_safe()."""
-    import re
-    safe = []
-    blocks = re.split(r"remark: Function Name: ", remarks)[1:]
-    for b in blocks:
-        name = b.split()[0]
-        m = re.search(r"k_proj_fwd_bf16_v([67])ILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)
-        m8 = re.search(r"k_proj_fwd_bf16_v8ILi(\d+)ELi(\d+)ELb([01])EE", name)
-        if not m and not m8:
-            continue
-        if m8:
-            ver, nt, mt, rem = 8, int(m8.group(1)), int(m8.group(2)), int(m8.group(3))
-        else:
-            ver, nt, mt, rem = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4) or 0)
-        num = lambda key: int(re.search(key + r": (\d+)", b).group(1))
-        ok = num("ScratchSize \\[bytes/lane\\]") == 0 and num("VGPRs Spill") == 0 and num("SGPRs Spill") == 0 \
-            and num("AGPRs") <= nt * (2 if ver == 8 else mt) * 4
-        if ok:
-            safe.append((ver, nt, mt, rem))
-    rows = "".join("  {%d, %d, %d, %d},\n" % t for t in sorted(set(safe)))
-    return ("// GENERATED by build.py from hipcc's kernel-resource-usage remarks -- do not edit.\n"
-            "static const int kSafe[][4] = {\n%s  {0, 0, 0, 0}};\n"
-            "extern \"C\" __attribute__((visibility(\"hidden\"))) int bprx_variant_safe(int ver, int nt, int mt, int rem) {\n"
-            "  for (int i = 0; kSafe[i][0]; ++i)\n"
-            "    if (kSafe[i][0] == ver && kSafe[i][1] == nt && kSafe[i][2] == mt && kSafe[i][3] == rem) return 1;\n"
-            "  return 0;\n}\n" % rows), sorted(set(safe))
-
-
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into fashionvisualexpl_recommend_amd/libbprx.so."""
     if not force and not needs_build():
@@ -69,8 +36,6 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, "build", src.rsplit(".", 1)[0] + ".o")
         cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", INCLUDE, "-I", CSRC,
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if src == "bprx_proj.hip":
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -79,17 +44,7 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-        if src == "bprx_proj.hip":
-            table_src, safe = _safe_table(out.decode(errors="replace"))
-            gen = os.path.join(HERE, "build", "bprx_safe_table.cpp")
-            with open(gen, "w") as f:
-                f.write(table_src)
-            gobj = gen[:-4] + ".o"
-            subprocess.check_call([_hipcc(), "-O2", "-fPIC", "-c", gen, "-o", gobj])
-            objs.append(gobj)
-            if verbose:
-                print("pipelined forward instantiations verified spill-free: %s" % safe, file=sys.stderr)
-        elif verbose and out:
+        if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
     cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
     subprocess.check_call(cmd)

@@ -126,12 +126,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
     if (h->SK < 1) h->SK = 1;
     if (h->SK > 256) h->SK = 256;
-    // defaults = the fastest measured variants (profiles/r01_sweeps.md); env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT override
-    h->fwd_variant = 12;   // v8: one balanced 5..8-wave workgroup per CU, staggered chunk order (falls back to v6 / v1)
-    // v3, 8 waves (256 columns) per workgroup, XCD-aware split placement, 3 tiles in flight (2: fp8 / wide projections)
-    h->bwd_variant = (cfg->feat_dtype == BPRX_F_FP8 || PS / 16 > 9) ? 26 : 42;
+    // BPRX_FWD_VARIANT=0: the plain forward kernel (the reference the streaming kernels are tested against); anything else:
+    // the per-shape policy of bprx_proj.hip (launch_fwd_nt / launch_bwd_nt)
+    h->fwd_variant = 4;
     if (const char *e = getenv("BPRX_FWD_VARIANT")) h->fwd_variant = atoi(e);
-    if (const char *e = getenv("BPRX_BWD_VARIANT")) h->bwd_variant = atoi(e);
     A(dalloc_zero(&h->dTu, U * d));
     A(dalloc_zero(&h->P, I * PS));
     A(dalloc_zero(&h->W, I * PS));
@@ -163,8 +161,6 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     h->seg_policy = (fits && !(cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 0;
     if (const char *e = getenv("BPRX_ITEM_MODE")) { const int v = atoi(e); h->seg_policy = h->seg_policy ? (v < 0 ? 0 : (v > 2 ? 2 : v)) : 0; }
     h->item_mode = 0;
-    if (vb && cfg->feat_dtype == BPRX_F_FP8 && h->bwd_variant < 8) h->bwd_variant = 26;                 // fp8: v3 only
-    if (h->seg_policy && vb && cfg->feat_dtype != BPRX_F_FP32 && h->bwd_variant < 8) h->bwd_variant = 8;  // reads Wb
     if (h->seg_policy) {
       // chunk list: the owners' regions (one slot per item + 4 per owner, <= 1024 owners; a last partial range) + the overflow list
       h->seg_lead_cap = (int64_t)(I + 8192 + 4 * 1024 + 2 * MB / 64 + 64 + 64);
@@ -346,9 +342,6 @@ extern "C" int bprx_tables_dirty(bprx_handle *h, void *stream) {
   // wrote the tables there (a NULL stream is synchronised instead)
   return h->bound ? bprx_launch_adam_reset(h, h->adam_t, (hipStream_t)stream) : BPRX_OK;
 }
-
-extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
-extern "C" int bprx_kernel_variant_safe(int ver, int nt, int mt, int rem) { return bprx_variant_safe(ver, nt, mt, rem); }
 
 extern "C" int bprx_set_hyper(bprx_handle *h, float lr, float reg) {
   if (!h) return BPRX_E_INVALID;

@@ -94,7 +94,7 @@ struct bprx_handle {
   int slist_slot;
   int SK_step;                    // split-K slabs written by this step's backward projection (<= SK)
   int num_cu;                     // compute units of the device (balanced forward grid)
-  int fwd_variant, bwd_variant;   // kernel variants (env BPRX_FWD_VARIANT / BPRX_BWD_VARIANT, read at create)
+  int fwd_variant;                // 0: the plain forward kernel (env BPRX_FWD_VARIANT, read at create), else the per-shape policy
   int64_t pending_B;              // B of the step between _begin and _end (0 = none)
   int pending_stage;              // 1 = bprx_step_begin_sparse done (user gradients final), 2 = whole _begin done
   const int32_t *pend_u, *pend_i, *pend_j;   // the pending step's index buffers (bprx_step_begin_dense)

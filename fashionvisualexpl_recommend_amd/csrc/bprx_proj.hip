@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_proj_fwd_bf16(const uint16_t *__restric
   // at the same moment.  `stagger` rotates the chunk order per workgroup (only the fp32 summation order changes).
   const int nchunks = D / KC;
   const int cshift = (stagger & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nchunks) : 0;
-  const bool dbg_skip_b = stagger & 2, dbg_skip_a = stagger & 4;   // timing-only ablations (wrong results)
+  constexpr bool dbg_skip_b = false, dbg_skip_a = false;
   const uint16_t *arow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -383,93 +383,14 @@ __global__ __launch_bounds__(NW * 64) void k_proj_fwd_rows(const uint16_t *__res
 
 // ------------------------------------------------------------------------------------------------------------
 // backward, bf16.  out[m, n] = sum_t F[t, m] * W[t, n]: both operands are stored t-major but the MFMA wants
-// the reduction index contiguous per lane, so 32-item tiles of F (128 columns) and W go through LDS and are
-// read back with the hardware transpose read ds_read_b64_tr_b16.  grid = (D/128 column ranges, SK item splits);
-// every workgroup writes its fp32 partial [128, PS] slab with plain stores; k_reduce_parts sums the SK slabs in a
-// fixed order (bit-reproducible, no float atomics).
+// the reduction index contiguous per lane, so 32-item tiles of F and W go through LDS and are read back with the
+// hardware transpose read ds_read_b64_tr_b16 (k_proj_bwd_bf16_v3 below).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int BT = 32;                 // items per tile = one MFMA k-step
-constexpr int FS_STRIDE = 128 + 16;    // 288-B rows: 8 rows x 32 B cover the 64 banks exactly once
-template <int NT>
-struct WsStride {                      // bf16 elements; (bytes/4) % 64 == 8
-  static constexpr int raw = NT * 16;
-  static constexpr int value = ((raw * 2 + 255 - 32) / 256) * 128 + 16;
-};
-
 __device__ __forceinline__ bf16x4 lds_tr16(const uint16_t *p) {
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
   return __builtin_bit_cast(bf16x4, v);
 }
-
-template <int NT>
-__global__ __launch_bounds__(256) void k_proj_bwd_bf16(const uint16_t *__restrict__ F, int nrows, int D,
-                                                       const float *__restrict__ W, int PS, float *__restrict__ part,
-                                                       int rows_per_split) {
-  constexpr int WS = WsStride<NT>::value;
-  __shared__ __attribute__((aligned(16))) uint16_t Fs[BT * FS_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[BT * WS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
-  const int m0 = blockIdx.x * 128;
-  const int tbeg = blockIdx.y * rows_per_split;
-  int tend = tbeg + rows_per_split;
-  if (tend > nrows) tend = nrows;
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int t0 = tbeg; t0 < tend; t0 += BT) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < BT * 16; idx += 256) {       // F tile: 32 rows x 16 chunks of 16 B
-      const int tr = idx >> 4, ch = idx & 15, t = t0 + tr;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < tend) v = *reinterpret_cast<const uint4 *>(F + ft_row(t, D) + ft_col(m0 + ch * 8));
-      *reinterpret_cast<uint4 *>(&Fs[tr * FS_STRIDE + ch * 8]) = v;
-    }
-    for (int idx = threadIdx.x; idx < BT * NT * 4; idx += 256) {   // W tile: fp32 -> bf16
-      const int tr = idx / (NT * 4), c4 = idx % (NT * 4), t = t0 + tr;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < tend) v = *reinterpret_cast<const float4 *>(W + (size_t)t * PS + c4 * 4);
-      uint2 pk;
-      pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-      pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-      *reinterpret_cast<uint2 *>(&Ws[tr * WS + c4 * 4]) = pk;
-    }
-    __syncthreads();
-    // lane 16g + 4qq + p supplies row (8g + qq [+4]) , columns 4p..4p+3 of a 16-column block and receives
-    // column i16 of rows 8g..8g+3 [+4]: exactly the 16x16x32 operand order  X[row/col i16][k = 8g + j].
-    bf16x8 a[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int col = (w * 2 + mt) * 16 + 4 * p;
-      bf16x4 lo = lds_tr16(&Fs[(8 * g + qq) * FS_STRIDE + col]);
-      bf16x4 hi = lds_tr16(&Fs[(8 * g + qq + 4) * FS_STRIDE + col]);
-      a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = nt * 16 + 4 * p;
-      bf16x4 lo = lds_tr16(&Ws[(8 * g + qq) * WS + col]);
-      bf16x4 hi = lds_tr16(&Ws[(8 * g + qq + 4) * WS + col]);
-      const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
-    }
-  }
-  float *slab = part + ((size_t)blockIdx.y * D + m0) * PS;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int m = (w * 2 + mt) * 16 + g * 4 + reg;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
-    }
-}
-
 
 // Wb (bf16 [I][PS]) = W (fp32), and W is re-zeroed for the next step in the same pass.
 __global__ __launch_bounds__(256) void k_cast_W(float *__restrict__ W, uint16_t *__restrict__ Wb, size_t n4) {
@@ -692,438 +613,11 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
 
 
 // ------------------------------------------------------------------------------------------------------------
-// forward v6: explicit ping-pong software pipeline (two named register sets, loop unrolled by two) whose global loads
-// and waits are written as inline asm.  hipcc kept re-timing every C++ formulation of the same pipeline (it sank the
-// [E|Bp]^T loads next to their LDS store and waited on same-iteration loads inside the MFMA block; see
-// profiles/r01_sweeps.md), so every chunk still paid a full memory round trip.  Here every loop load is an asm
-// `global_load_dwordx4`; the compiler sees no VMEM event, inserts no vmcnt of its own, and the two counted waits per
-// half-iteration are placed by hand (vmcnt retires in issue order: B pieces first, then the A fragments):
-//   before parking chunk c+1's B pieces:  vmcnt(KS*MT)        -> only the A fragments of c+1 stay in flight
-//   before the MFMAs of chunk c:          vmcnt(NT + KS*MT)   -> everything of c+1 stays in flight
-// Each register is then passed through an empty asm ("+v") so no use can be scheduled above its wait.
-// ------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-
-__device__ __forceinline__ void asm_gload(i32x4 &dst, const void *p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void asm_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void asm_tie(i32x4 &r) { asm volatile("" : "+v"(r)); }
-// LDS read the compiler can neither sink nor serialize (it turns  read-all-then-MFMA  back into  read, wait, MFMA  per
-// fragment to save registers); completion is waited for with counted lgkmcnt (LDS operations return in order).
-__device__ __forceinline__ void asm_dsread(i32x4 &dst, const void *lds_ptr) {
-  const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void *)lds_ptr;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a) : "memory");
-}
-__device__ __forceinline__ void asm_lgkmcnt(int n) {   // n is a constant after unrolling: one case survives
-  switch (n) {
-    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
-  }
-}
-
-// ABL: compile-time timing-only ablations (wrong results): 1 no global loads after the first issue, 2 no MFMA,
-// 4 no LDS reads, 8 no LDS writes
-template <int NT, int MT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void k_proj_fwd_bf16_v6(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger,
-                                                          const float *__restrict__ /*pscale: bf16 only*/) {
-  constexpr int BSS = KC + 16;
-  constexpr int KS = KC / 32;
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * BSS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int row0 = (blockIdx.x * 4 + w) * MT * 16;
-  const uint16_t *arow[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int t = row0 + mt * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + ft_row(item, D) + q * 8;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
-  const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 8;
-  const int nch = D / KC;
-  const int cshift = (stagger & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nch) : 0;
-  const bool nobar = stagger & 2;                       // timing-only ablations (wrong results): no barriers /
-  const int amask = (stagger & 4) ? 0 : -1;             // every A load re-reads chunk 0 (cache hits)
-  const int bmask = (stagger & 8) ? 0 : -1;             // every B load re-reads chunk 0
-  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x4 bX[NT], bY[NT], aX[KS][MT], aY[KS][MT];
-#define V6_ISSUE(c_, BR, AR)                                                                                          \
-  {                                                                                                                   \
-    const int k1 = kof(c_);                                                                                           \
-    if (!(ABL & 1) || c_ == 0) {                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_gload(BR[t], &Et[et_idx(t * 16 + bn, (k1 & bmask) + bk, NT * 16)]);      \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_gload(AR[ks][mt], arow[mt] + ((size_t)((k1 & amask) >> 7) << 12) + ks * 32);                                                               \
-    }                                                                                                                 \
-  }
-#define V6_PARK(buf_, BR, NWAIT)                                                                                      \
-  {                                                                                                                   \
-    if (!(ABL & 1)) asm_vmcnt<NWAIT>();                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) asm_tie(BR[t]);                                                    \
-    if (!(ABL & 8))                                                                                                   \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
-        *reinterpret_cast<i32x4 *>(&Bs[buf_][(t * 16 + bn) * BSS + bk]) = BR[t];                                      \
-  }
-#define V6_COMPUTE(buf_, AR, NWAIT)                                                                                   \
-  {                                                                                                                   \
-    if (!(ABL & 1)) asm_vmcnt<NWAIT>();                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_tie(AR[ks][mt]);                                                                                          \
-    /* B fragments stream from LDS through a window of LWIN reads in flight; fragment f = ks*NT + nt */               \
-    i32x4 bfr[KS * NT];                                                                                               \
-    if (!(ABL & 4))                                                                                                   \
-    _Pragma("unroll") for (int f = 0; f < LWIN && f < KS * NT; ++f)                                                   \
-        asm_dsread(bfr[f], &Bs[buf_][((f % NT) * 16 + r) * BSS + (f / NT) * 32 + q * 8]);                             \
-    _Pragma("unroll") for (int f = 0; f < KS * NT; ++f) {                                                             \
-      const int left = KS * NT - 1 - f;                                                                               \
-      if (!(ABL & 4)) asm_lgkmcnt(left < LWIN - 1 ? left : LWIN - 1);                                                 \
-      asm_tie(bfr[f]);                                                                                                \
-      if (!(ABL & 2))                                                                                                 \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                               \
-          acc[mt][f % NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AR[f / NT][mt]),       \
-                                                                    __builtin_bit_cast(bf16x8, bfr[f]), acc[mt][f % NT], 0, 0, 0); \
-      if (!(ABL & 4) && f + LWIN < KS * NT)                                                                           \
-        asm_dsread(bfr[f + LWIN], &Bs[buf_][(((f + LWIN) % NT) * 16 + r) * BSS + ((f + LWIN) / NT) * 32 + q * 8]);    \
-    }                                                                                                                 \
-  }
-  constexpr int LWIN = 10;   // LDS reads in flight per wave (lgkmcnt counts to 15)
-  constexpr int NA = KS * MT, NALL = NT + KS * MT;
-  V6_ISSUE(0, bX, aX)
-  V6_PARK(0, bX, NA)
-  __syncthreads();
-  // No branch may separate an asm load from its wait: at a control-flow join the compiler is free to copy what it
-  // believes are finished values (observed: v_mov of in-flight registers in an else-branch -> garbage).  The loop
-  // body is therefore straight-line; the last prefetch re-reads chunk nch-1 instead of being skipped.
-  for (int c = 0; c < nch; c += 2) {            // nch is even (D % 256 == 0 is required by the launcher)
-    V6_ISSUE(c + 1, bY, aY)
-    V6_COMPUTE(0, aX, NALL)
-    V6_PARK(1, bY, NA)
-    if (!nobar) __syncthreads();
-    const int cn = c + 2 < nch ? c + 2 : nch - 1;
-    V6_ISSUE(cn, bX, aX)
-    V6_COMPUTE(1, aY, NALL)
-    V6_PARK(0, bX, NA)
-    if (!nobar) __syncthreads();
-  }
-  asm_vmcnt<0>();
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) asm_tie(aX[ks][mt]);
-#undef V6_ISSUE
-#undef V6_PARK
-#undef V6_COMPUTE
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = row0 + mt * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg];
-      }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// forward v8: the v6 pipeline on ONE 8-wave workgroup per CU with a balanced share of the 16-row tiles.
-// Measured (scripts/fwd_scale.py, scripts/probe/ldpat.hip, profiles/r01_sweeps.md): v6 streams F at the ~4.9 TB/s this
-// access pattern reaches on the chip ONLY when every CU holds the same number of workgroups (32768 or 65536 items);
-// co-resident workgroups do not overlap, so 50000 items = 391 workgroups of 128 items (two on 135 CUs, one on the
-// rest) take as long as 65536 items.  Here every CU gets T/G tiles (+-1) and reads the [E|Bp]^T chunks once.
-//   grid G (= #CUs while T <= 16 G); workgroup g owns tiles [g*T/G, (g+1)*T/G), at most 16, and has as many waves
-//   (5..8) as give every wave TWO tiles (one when the launch is small): the waves walk the chunks in lockstep, so a
-//   wave with one tile among waves with two buys nothing (12 tiles on 8 waves: 95.6 us; on 6-7 waves: see sweeps).
-//   The pipeline body is instantiated for 2 and for 1 row tile and picked per wave (same barrier sequence in both) --
-//   a repeated dummy tile would cost its full load-issue time.
-// ------------------------------------------------------------------------------------------------------------
-// NWMIN: smallest workgroup (waves) the launcher may pick for this instantiation (fixes the B pieces per thread)
-template <int NT, int MT, int NWMIN, bool F8>
-__device__ __forceinline__ void v8_body(const uint16_t *const (&arow)[2], const uint16_t *__restrict__ Et, uint16_t (*Bs)[NT * 16 * (KC + 16)],
-                                        f32x4 (&acc)[2][NT], int D, int cshift, int r, int q, int et_chunk) {
-  constexpr int BSS = KC + 16;
-  constexpr int KS = KC / 32;
-  constexpr int NPIECE = NT * 16 * (KC / 8);              // 16-B pieces of one [E|Bp]^T chunk (contiguous in Et)
-  constexpr int NBP = (NPIECE + NWMIN * 64 - 1) / (NWMIN * 64);   // pieces per thread for the smallest workgroup;
-  // piece x of this thread: tid + x*blockDim, surplus slots clamp onto piece NPIECE-1 (one address per wave); the
-  // offsets are recomputed at every use (two VALU ops) instead of living in 2*NBP registers
-  const int tid = threadIdx.x, bdim = (int)blockDim.x;
-  auto piece = [&](int x) { const int pc = tid + x * bdim; return pc < NPIECE ? pc : NPIECE - 1; };
-  const int nch = D / KC;
-  auto kof = [&](int c) { int ce = c + cshift; if (ce >= nch) ce -= nch; return ce * KC; };
-  i32x4 bX[NBP], bY[NBP], aX[KS][MT], aY[KS][MT];
-#define V8_ISSUE(c_, BR, AR)                                                                                          \
-  {                                                                                                                   \
-    const int k1 = kof(c_);                                                                                           \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_gload(BR[x], &Et[(size_t)(k1 >> 7) * et_chunk + piece(x) * 8]); \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_gload(AR[ks][mt], arow[mt] + ((size_t)(k1 >> 7) << 12) + ks * 32);   /* k1 % 128 == 0: ft_col(k1) + ks*32 */                                                               \
-  }
-#define V8_PARK(buf_, BR, NWAIT)                                                                                      \
-  {                                                                                                                   \
-    asm_vmcnt<NWAIT>();                                                                                               \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x) asm_tie(BR[x]);                                                   \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                 \
-      const int pc = piece(x);                                                                                        \
-      *reinterpret_cast<i32x4 *>(&Bs[buf_][(pc / (KC / 8)) * BSS + (pc % (KC / 8)) * 8]) = BR[x];                     \
-    }                                                                                                                 \
-  }
-#define V8_COMPUTE(buf_, AR, NWAIT)                                                                                   \
-  {                                                                                                                   \
-    asm_vmcnt<NWAIT>();                                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)               \
-        asm_tie(AR[ks][mt]);                                                                                          \
-    i32x4 bfr[KS * NT];                                                                                               \
-    _Pragma("unroll") for (int f = 0; f < LWIN8 && f < KS * NT; ++f)                                                  \
-        asm_dsread(bfr[f], &Bs[buf_][((f % NT) * 16 + r) * BSS + (f / NT) * 32 + q * 8]);                             \
-    _Pragma("unroll") for (int f = 0; f < KS * NT; ++f) {                                                             \
-      const int left = KS * NT - 1 - f;                                                                               \
-      asm_lgkmcnt(left < LWIN8 - 1 ? left : LWIN8 - 1);                                                               \
-      asm_tie(bfr[f]);                                                                                                \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                               \
-          acc[mt][f % NT] = mfma_frag<F8>(AR[f / NT][mt], bfr[f], acc[mt][f % NT]);                                   \
-      if (f + LWIN8 < KS * NT)                                                                                        \
-        asm_dsread(bfr[f + LWIN8], &Bs[buf_][(((f + LWIN8) % NT) * 16 + r) * BSS + ((f + LWIN8) / NT) * 32 + q * 8]); \
-    }                                                                                                                 \
-  }
-  constexpr int LWIN8 = NT <= 6 ? 8 : (F8 ? 3 : 4);   // LDS fragment reads in flight (register budget of the wide instantiations)
-  constexpr int NA = KS * MT, NALL = NBP + KS * MT;
-  V8_ISSUE(0, bX, aX)
-  V8_PARK(0, bX, NA)
-  __syncthreads();
-  for (int c = 0; c < nch; c += 2) {            // straight-line body (see v6); nch is even
-    V8_ISSUE(c + 1, bY, aY)
-    V8_COMPUTE(0, aX, NALL)
-    V8_PARK(1, bY, NA)
-    __syncthreads();
-    const int cn = c + 2 < nch ? c + 2 : nch - 1;
-    V8_ISSUE(cn, bX, aX)
-    V8_COMPUTE(1, aY, NALL)
-    V8_PARK(0, bX, NA)
-    __syncthreads();
-  }
-  asm_vmcnt<0>();
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) asm_tie(aX[ks][mt]);
-#undef V8_ISSUE
-#undef V8_PARK
-#undef V8_COMPUTE
-}
-
-// NWMAX = 8 (two waves per SIMD, 256 registers each) up to NT = 9; NWMAX = 4 (one wave per SIMD, the unified 512-register
-// file: accumulators in AGPRs) for the wide projections (d >= 112).
-template <int NT, int NWMAX, bool F8>
-__global__ __launch_bounds__(NWMAX * 64, 1) void k_proj_fwd_bf16_v8(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger,
-                                                          const float *__restrict__ pscale, int tiles_per_wave, int n0) {
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NT * 16 * (KC + 16)];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int T = (nrows + 15) >> 4;
-  const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
-  int tile[2];
-  const uint16_t *arow[2];
-  const int first = t0 + w * tiles_per_wave;                               // tiles_per_wave is 1 or 2
-  const int nlive = (first < t1 ? 1 : 0) + ((tiles_per_wave == 2 && first + 1 < t1) ? 1 : 0);   // wave-uniform
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    tile[mt] = first + mt;
-    if (tile[mt] >= t1) tile[mt] = t1 > t0 ? t1 - 1 : 0;                  // only read by a wave without work
-    int t = tile[mt] * 16 + r;
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    arow[mt] = F + ft_row(item, D) + q * 8;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the compiler's own prologue loads are done
-  const int nch = D / KC;
-  const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NWMIN = NWMAX == 8 ? (NT <= 7 ? 5 : 8) : NWMAX;   // wide tiles: always 8 waves (fewer B pieces per thread)
-  // this launch covers the NT column tiles [n0, n0 + NT*16) of the PS-wide projection (wide projections are split
-  // over two launches): the chunk images are PS*128 elements apart, the rows of a chunk contiguous from n0*128
-  const uint16_t *Et0 = Et + (size_t)n0 * 128;
-  if (nlive == 2) v8_body<NT, 2, NWMIN, F8>(arow, Et0, Bs, acc, D, cshift, r, q, PS * 128);
-  else v8_body<NT, 1, NWMIN, F8>(arow, Et0, Bs, acc, D, cshift, r, q, PS * 128);   // nlive == 0: a spare wave repeats a tile
-  const float ps = F8 ? *pscale : 1.0f;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    if (mt >= nlive) continue;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = tile[mt] * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + n0 + nt * 16 + r] = acc[mt][nt][reg] * ps;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// forward v9: as v8 (one balanced workgroup per CU), but the A operand (feature rows) is loaded like the backward
-// kernel loads its tiles -- every thread moves contiguous 16-B pieces of the tiled F (a 16-row tile x 128-column chunk
-// is one contiguous 4-KB run), registers -> LDS, and the MFMA fragments are read from LDS -- instead of 16-row x 64-B
-// fragment loads straight into VGPRs.  Plain C++ (the compiler keeps counted vmcnt for unconditional loads, see the
-// backward kernel); PD9 chunks in flight in registers, one LDS image, two barriers per chunk.
-// ------------------------------------------------------------------------------------------------------------
-template <int NT, bool F8>
-__global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__restrict__ F, const int32_t *__restrict__ rows,
-                                                          int nrows, int nitems, int D, const uint16_t *__restrict__ Et,
-                                                          float *__restrict__ P, int PS, int32_t *errflag, int stagger,
-                                                          const float *__restrict__ pscale, int tiles_per_wave, int n0) {
-  constexpr int RB = 288;                                  // LDS row stride, bytes (256 B of a chunk row + 32)
-  constexpr int APT = 8;                                   // A pieces per thread and chunk (16 tiles x 256 pieces / 512)
-  constexpr int NPIECE = NT * 16 * 16;                     // 16-B pieces of one [E|Bp]^T chunk
-  constexpr int NBP = (NPIECE + 5 * 64 - 1) / (5 * 64);
-  constexpr int PD9 = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds9[];
-  unsigned char *As = lds9;                                // [256 rows][RB]
-  unsigned char *Bs = lds9 + 256 * RB;                     // [NT*16 rows][RB]
-  const int tid = threadIdx.x, bdim = (int)blockDim.x;
-  const int lane = tid & 63, w = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int T = (nrows + 15) >> 4;
-  const int t0 = (int)(((long long)blockIdx.x * T) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
-  const int ntile = t1 - t0, napiece = ntile * 256;        // 16 rows x 16 pieces per tile
-  const int first = w * tiles_per_wave;                    // this wave's tiles, workgroup-local numbering
-  const int nlive = (first < ntile ? 1 : 0) + ((tiles_per_wave == 2 && first + 1 < ntile) ? 1 : 0);
-  // per A piece of this thread: where its row starts in the tiled F (pieces past the end repeat the last one)
-  const uint16_t *abase[APT];
-  int alds[APT];
-#pragma unroll
-  for (int x = 0; x < APT; ++x) {
-    int pc = tid + x * bdim;
-    pc = pc < napiece ? pc : (napiece > 0 ? napiece - 1 : 0);
-    int t = t0 * 16 + (pc >> 4);
-    if (t >= nrows) t = nrows - 1;
-    int item = rows ? rows[t] : t;
-    if ((unsigned)item >= (unsigned)nitems) { *errflag = 2; item = 0; }
-    abase[x] = F + ft_row(item, D) + (pc & 15) * 8;
-    alds[x] = (pc >> 4) * RB + (pc & 15) * 16;
-  }
-#define V9_BPIECE(x) ((tid + (x) * bdim) < NPIECE ? (tid + (x) * bdim) : NPIECE - 1)   /* no lambda: a by-reference capture
-                                                                                          puts the arrays in scratch */
-  const uint16_t *Et0 = Et + (size_t)n0 * 128;
-  const int nch = D / KC;
-  const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x4_t areg0[APT], areg1[APT], areg2[APT], breg0[NBP], breg1[NBP], breg2[NBP];   // first-class vectors: a uint4 struct copy becomes a memcpy
-                                                            // through a private array the compiler then keeps in scratch
-#define V9_ISSUE(ST, C)                                                                                              \
-  {                                                                                                                  \
-    int cc_ = (C);                                                                                                   \
-    cc_ = cc_ < nch ? cc_ : nch - 1;                                                                                 \
-    int ce_ = cc_ + cshift;                                                                                          \
-    if (ce_ >= nch) ce_ -= nch;                                                                                      \
-    const size_t kb_ = (size_t)ce_ << 12;                     /* chunk ce_ of a tiled row: ce_ * 4096 units */       \
-    _Pragma("unroll") for (int x = 0; x < APT; ++x) areg##ST[x] = *reinterpret_cast<const i32x4_t *>(abase[x] + kb_);  \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x)                                                                  \
-        breg##ST[x] = *reinterpret_cast<const i32x4_t *>(Et0 + (size_t)ce_ * (PS * 128) + V9_BPIECE(x) * 8);           \
-  }
-#define V9_COMMIT(ST)                                                                                                \
-  {                                                                                                                  \
-    _Pragma("unroll") for (int x = 0; x < APT; ++x) *reinterpret_cast<i32x4_t *>(As + alds[x]) = areg##ST[x];         \
-    _Pragma("unroll") for (int x = 0; x < NBP; ++x) {                                                                \
-      const int pc = V9_BPIECE(x);                                                                                   \
-      *reinterpret_cast<i32x4_t *>(Bs + (pc >> 4) * RB + (pc & 15) * 16) = breg##ST[x];                                \
-    }                                                                                                                \
-  }
-#define V9_COMPUTE()                                                                                                 \
-  if (nlive > 0) {                                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < KC / 32; ++ks) {                                                         \
-      const i32x4_t a0 = *reinterpret_cast<const i32x4_t *>(As + (first * 16 + r) * RB + ks * 64 + q * 16);          \
-      const i32x4_t a1 = *reinterpret_cast<const i32x4_t *>(As + ((nlive == 2 ? first + 1 : first) * 16 + r) * RB + ks * 64 + q * 16); \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                            \
-        const i32x4_t b = *reinterpret_cast<const i32x4_t *>(Bs + (nt * 16 + r) * RB + ks * 64 + q * 16);            \
-        acc[0][nt] = mfma_frag<F8>(a0, b, acc[0][nt]);                                                               \
-        acc[1][nt] = mfma_frag<F8>(a1, b, acc[1][nt]);   /* a wave with one tile computes it twice, stores once */   \
-      }                                                                                                              \
-    }                                                                                                                \
-  }
-  // three chunks in flight (stages written out so that the staging registers keep static names); chunks past the end are
-  // clamped re-reads of the last chunk and are never committed
-  V9_ISSUE(0, 0)
-  V9_ISSUE(1, 1)
-  V9_ISSUE(2, 2)
-  for (int c0 = 0; c0 < nch; c0 += 3) {
-    __syncthreads();
-    V9_COMMIT(0)
-    __syncthreads();
-    V9_ISSUE(0, c0 + 3)
-    V9_COMPUTE()
-    if (c0 + 1 < nch) {                                       // workgroup-uniform
-      __syncthreads();
-      V9_COMMIT(1)
-      __syncthreads();
-      V9_ISSUE(1, c0 + 4)
-      V9_COMPUTE()
-    }
-    if (c0 + 2 < nch) {
-      __syncthreads();
-      V9_COMMIT(2)
-      __syncthreads();
-      V9_ISSUE(2, c0 + 5)
-      V9_COMPUTE()
-    }
-  }
-#undef V9_COMPUTE
-#undef V9_ISSUE
-#undef V9_COMMIT
-#undef V9_BPIECE
-  const float ps = F8 ? *pscale : 1.0f;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    if (mt >= nlive) continue;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int t = (t0 + first + mt) * 16 + q * 4 + reg;
-      if (t < nrows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + n0 + nt * 16 + r] = acc[mt][nt][reg] * ps;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// forward v10: v8's balanced one-workgroup-per-CU shape, but the A operand arrives as CONTIGUOUS pieces of the tiled F --
+// forward v10 (the streaming forward of every projection of up to nine column tiles, bf16 and fp8; wider bf16 projections in
+// column-range passes; wide fp8 ones: k_proj_fwd_f8s).  ONE balanced workgroup per CU that owns T/CUs (+-1) of the 16-row tiles,
+// with as many waves (5..8) as give every wave two tiles (round 1: co-resident smaller workgroups did not overlap and the
+// launch cost (max workgroups on a CU) x (one workgroup's time): 50 000 items cost as much as 65 536); the A operand arrives as
+// CONTIGUOUS pieces of the tiled F --
 // a 16-row tile x 128-column chunk is one contiguous 4-KB run, lane l moves 16 B at l*16 (+1 KB per load), exactly the load
 // shape of the backward kernel (which streams F at the device's ceiling) -- into a WAVE-PRIVATE LDS area, from which the
 // MFMA fragments are read back with ds_read_b128.  v8's fragment loads take 16 rows x 64 B per instruction: half of every
@@ -1131,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void k_proj_fwd_bf16_v9(const uint16_t *__r
 // detour costs no barrier (v9 tried this load shape with a workgroup-shared image and two barriers per chunk and lost).
 // Plain C++ with scheduling fences; B as in v8 (chunk through a double-buffered shared LDS image, one barrier per chunk).
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, int MT, bool F8>
+template <int NT, int MT, bool F8, bool NTL>
 __device__ __forceinline__ void v10_body(const uint16_t *const (&asrc)[2], const uint16_t *__restrict__ Et, unsigned char *lds,
                                          unsigned char *myA, f32x4 (&acc)[2][NT], int D, int cshift, int lane, int et_chunk) {
   constexpr int BSB = (KC + 16) * 2;                    // B row stride in bytes (288)
@@ -1149,7 +643,7 @@ __device__ __forceinline__ void v10_body(const uint16_t *const (&asrc)[2], const
     int ce_ = (c_) + cshift;                                                                                          \
     if (ce_ >= nch) ce_ -= nch;                                                                                       \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int x = 0; x < 4; ++x)                   \
-        AR[mt][x] = ld_stream16<!F8>(asrc[mt] + ((size_t)ce_ << 12) + x * 512 + lane * 8);                          \
+        AR[mt][x] = ld_stream16<NTL>(asrc[mt] + ((size_t)ce_ << 12) + x * 512 + lane * 8);                          \
     const uint16_t *bc_ = Et + (size_t)ce_ * et_chunk;                                                                \
     _Pragma("unroll") for (int x = 0; x < NBR; ++x) {                                                                 \
       int pc = tid + x * bdim;                                                                                        \
@@ -1206,10 +700,13 @@ __device__ __forceinline__ void v10_body(const uint16_t *const (&asrc)[2], const
 #undef V10_COMPUTE
 }
 
-template <int NT, bool F8>
+// NTL: the feature loads carry `nt` (tables that cannot stay in the Infinity Cache between the two passes of a step);
+// n0: first column of this launch's column range (NT tiles from there; 0 unless a wide projection is covered in passes).
+template <int NT, bool F8, bool NTL>
 __global__ __launch_bounds__(512) void k_proj_fwd_bf16_v10(const uint16_t *__restrict__ F, int nrows, int D,
                                                            const uint16_t *__restrict__ Et, float *__restrict__ P, int PS,
-                                                           const float *__restrict__ pscale, int stagger, int tiles_per_wave) {
+                                                           const float *__restrict__ pscale, int stagger, int tiles_per_wave,
+                                                           int n0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_v10[];   // Bs[2] | As[waves][2 tiles][16 rows][288 B]
   constexpr int BSB = (KC + 16) * 2;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1233,8 +730,9 @@ __global__ __launch_bounds__(512) void k_proj_fwd_bf16_v10(const uint16_t *__res
   const int nch = D / KC;
   const int cshift = (stagger & 1) ? (int)(blockIdx.x % (unsigned)nch) : 0;
   unsigned char *myA = lds_v10 + 2 * NT * 16 * BSB + w * (2 * 16 * BSB);
-  if (nlive == 2) v10_body<NT, 2, F8>(asrc, Et, lds_v10, myA, acc, D, cshift, lane, PS * 128);
-  else v10_body<NT, 1, F8>(asrc, Et, lds_v10, myA, acc, D, cshift, lane, PS * 128);
+  // (chunk-major image: chunk c holds rows [0, PS) x 128 k; this launch's columns start at row n0 of every chunk)
+  if (nlive == 2) v10_body<NT, 2, F8, NTL>(asrc, Et + (size_t)n0 * 128, lds_v10, myA, acc, D, cshift, lane, PS * 128);
+  else v10_body<NT, 1, F8, NTL>(asrc, Et + (size_t)n0 * 128, lds_v10, myA, acc, D, cshift, lane, PS * 128);
   const float ps = F8 ? *pscale : 1.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -1244,7 +742,7 @@ __global__ __launch_bounds__(512) void k_proj_fwd_bf16_v10(const uint16_t *__res
       const int t = (first + mt) * 16 + q * 4 + reg;
       if (t < nrows) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + nt * 16 + r] = acc[mt][nt][reg] * ps;
+        for (int nt = 0; nt < NT; ++nt) P[(size_t)t * PS + n0 + nt * 16 + r] = acc[mt][nt][reg] * ps;
       }
     }
   }
@@ -1496,83 +994,10 @@ __global__ __launch_bounds__(256) void k_proj_bwd_f32(const float *__restrict__ 
   }
 }
 
-// The same two products, parallelised for what the reference's CLI defaults produce (train_rec.py:23,33-35: batch 256, fp32
+// The same products, parallelised for what the reference's CLI defaults produce (train_rec.py:23,33-35: batch 256, fp32
 // features, k = 128, d = 20 -- a few hundred listed rows, 21 output columns): the kernels above give a wave 21 busy lanes
 // and a 4096-step serial loop (975 us + 158 us per step at I = 10 000, D = 4096).  Same arithmetic (every product and every
-// sum in fp64), other summation order.
-//   forward: a block = FT rows x 32 columns; its 8 lane groups of 32 take every 8th 4-element piece of k (F row pieces are
-//   16-B broadcasts, E rows are coalesced over the columns); the 8 partial sums meet in LDS, fixed order.
-constexpr int F32_RT = 2, F32_NSL = 32;                    // rows per block, k slices per block (1024 threads)
-__global__ __launch_bounds__(1024) void k_proj_fwd_f32_tile(const float *__restrict__ F, const int32_t *__restrict__ rows,
-                                                            int nrows, const int32_t *__restrict__ nrows_dev, int scatter,
-                                                            int nitems, int D, const float *__restrict__ E,
-                                                            const float *__restrict__ Bp, int d, float *__restrict__ P, int PS,
-                                                            int32_t *errflag) {
-  __shared__ double red[F32_NSL][F32_RT][32];
-  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
-  const int t0 = blockIdx.x * F32_RT;
-  if (t0 >= nrows) return;                                  // (block-uniform)
-  const int ks = threadIdx.x >> 5, n = threadIdx.x & 31, col = blockIdx.y * 32 + n;
-  const float *f[F32_RT];
-  int item[F32_RT];
-#pragma unroll
-  for (int r = 0; r < F32_RT; ++r) {
-    const int t = t0 + r < nrows ? t0 + r : nrows - 1;      // (rows past the end: recomputed, not stored)
-    int it = rows ? rows[t] : t;
-    if ((unsigned)it >= (unsigned)nitems) { *errflag = 2; it = 0; }
-    item[r] = it;
-    f[r] = F + (size_t)it * D;
-  }
-  double acc[F32_RT];
-#pragma unroll
-  for (int r = 0; r < F32_RT; ++r) acc[r] = 0.0;
-  const bool isE = col < d, isB = col == d;
-  // a slice's k pieces: ks*4, ks*4 + 128, ...; PT pieces per trip, all loads of a trip before its arithmetic (the loop is a
-  // chain of memory round trips: 8 of them at D = 4096)
-  constexpr int STEP = F32_NSL * 4, PT = 4;
-  for (int kb = ks * 4; kb < D; kb += PT * STEP) {          // D % 4 == 0 (launcher)
-    int kq[PT];
-    double wq[PT];
-#pragma unroll
-    for (int x = 0; x < PT; ++x) {                          // (pieces past the end: the first one again, weight 0)
-      const bool in = kb + x * STEP < D;
-      kq[x] = in ? kb + x * STEP : kb;
-      wq[x] = in ? 1.0 : 0.0;
-    }
-    float e[PT][4];
-    float4 v[F32_RT][PT];
-#pragma unroll
-    for (int x = 0; x < PT; ++x)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) e[x][q] = isE ? E[(size_t)(kq[x] + q) * d + col] : (isB ? Bp[kq[x] + q] : 0.f);
-#pragma unroll
-    for (int r = 0; r < F32_RT; ++r)
-#pragma unroll
-      for (int x = 0; x < PT; ++x) v[r][x] = *reinterpret_cast<const float4 *>(f[r] + kq[x]);
-#pragma unroll
-    for (int r = 0; r < F32_RT; ++r)
-#pragma unroll
-      for (int x = 0; x < PT; ++x) {
-        acc[r] += wq[x] * ((double)v[r][x].x * (double)e[x][0]);
-        acc[r] += wq[x] * ((double)v[r][x].y * (double)e[x][1]);
-        acc[r] += wq[x] * ((double)v[r][x].z * (double)e[x][2]);
-        acc[r] += wq[x] * ((double)v[r][x].w * (double)e[x][3]);
-      }
-  }
-#pragma unroll
-  for (int r = 0; r < F32_RT; ++r) red[ks][r][n] = acc[r];
-  __syncthreads();
-  if (ks < F32_RT && (isE || isB)) {                        // lane group r sums row r
-    const int r = ks;
-    if (t0 + r < nrows) {
-      double sum = red[0][r][n];
-      for (int q = 1; q < F32_NSL; ++q) sum += red[q][r][n];
-      const size_t o = scatter ? (size_t)item[r] : (size_t)(t0 + r);
-      P[o * PS + col] = (float)sum;
-    }
-  }
-}
-
+// sum in fp64), other summation order.  Forward: k_proj_fwd_f32_mfma below (fp64 matrix instruction).
 //   backward over a row list: a block = 8 values of k x 32 columns; its 32 lane groups take every 32nd listed row (the W row
 //   is coalesced over the columns, the 8 feature values are two 16-B broadcasts); partial sums meet in LDS, fixed order.
 constexpr int F32_NRS = 32, F32_KV = 8;
@@ -1694,104 +1119,9 @@ __global__ __launch_bounds__(1024) void k_proj_fwd_f32_mfma(const float *__restr
   }
 }
 
-//   backward over a row list: block = 16 values of k x 16 columns, its 4 waves take every 4th 16-row piece of the list.
-__global__ __launch_bounds__(256) void k_proj_bwd_f32_mfma(const float *__restrict__ F, int nrows, int D,
-                                                           const float *__restrict__ W, int d, int PS, float *__restrict__ dEp,
-                                                           const int32_t *__restrict__ rows, const int32_t *__restrict__ nrows_dev) {
-  __shared__ double red[4][4][64];
-  if (nrows_dev) { const int n = *nrows_dev; nrows = n < nrows ? n : nrows; }
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
-  const int k0 = blockIdx.x * 16, col = blockIdx.y * 16 + i;
-  const bool on = col <= d;
-  f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
-  const int nchunk = (nrows + 15) >> 4;
-  for (int c = w; c < nchunk; c += 4) {
-    const int tb = (c << 4) + 4 * kq;
-    int it[4];
-    float wv[4], fv[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int t = tb + s4;
-      it[s4] = rows ? rows[t < nrows ? t : nrows - 1] : (t < nrows ? t : nrows - 1);
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      fv[s4] = F[(size_t)it[s4] * D + k0 + i];
-      wv[s4] = (on && tb + s4 < nrows) ? W[(size_t)it[s4] * PS + col] : 0.f;     // (rows past the end: weight 0)
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fv[s4], (double)wv[s4], acc, 0, 0, 0);
-  }
-  red[w][0][lane] = acc.x; red[w][1][lane] = acc.y; red[w][2][lane] = acc.z; red[w][3][lane] = acc.w;
-  __syncthreads();
-  {                                                         // wave r sums result register r of the 4 partial tiles
-    const double sum = (red[0][w][lane] + red[1][w][lane]) + (red[2][w][lane] + red[3][w][lane]);
-    const int kk = k0 + (lane >> 4) + 4 * w, oc = blockIdx.y * 16 + (lane & 15);
-    if (oc < d) dEp[(size_t)kk * d + oc] = (float)sum;
-    else if (oc == d) dEp[(size_t)D * d + kk] = (float)sum;
-  }
-}
-
-extern "C" int bprx_variant_safe(int ver, int nt, int mt, int rem);   // generated at build time (build.py)
 
 // Deq: row width in bf16-sized units (fp8 rows are addressed as bf16 rows of half the width)
 #define FWD_ARGS (const uint16_t *)h->Ft, rows, (int)nrows, h->cfg.num_items, Deq, (const uint16_t *)h->Et, Pout, h->PS, h->errflag
-template <int NT>
-void launch_v9(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
-               const float *pscale, int stagger, int n0) {
-  const int64_t T = (nrows + 15) / 16;
-  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
-  int64_t G = (T + 15) / 16;
-  if (G < ncu) G = T < ncu ? T : ncu;
-  else G = (G + ncu - 1) / ncu * ncu;
-  const int tpw_max = (int)((T + G - 1) / G);
-  const int per_wave = tpw_max > 8 ? 2 : 1;
-  int nw = (tpw_max + per_wave - 1) / per_wave;
-  if (nw < 5) nw = 5;
-  const size_t lds = (size_t)(256 + NT * 16) * 288;
-  if (f8) {
-    auto kfn = k_proj_fwd_bf16_v9<NT, true>;
-    (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, FWD_ARGS, stagger, pscale, per_wave, n0);
-  } else {
-    auto kfn = k_proj_fwd_bf16_v9<NT, false>;
-    (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, FWD_ARGS, stagger, pscale, per_wave, n0);
-  }
-}
-
-template <int NT>
-void launch_v8(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
-               const float *pscale, int stagger, int n0) {
-  constexpr int NWMAX = 8, NWMIN = NT <= 7 ? 5 : 8;   // must match the kernel's NWMIN
-  const int64_t T = (nrows + 15) / 16;
-  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
-  int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
-  if (G < ncu) G = T < ncu ? T : ncu;
-  else G = (G + ncu - 1) / ncu * ncu;
-  const int tpw_max = (int)((T + G - 1) / G);                 // most tiles any workgroup owns (<= 2 NWMAX)
-  const int per_wave = tpw_max > NWMAX ? 2 : 1;
-  int nw = (tpw_max + per_wave - 1) / per_wave;
-  if (nw < NWMIN) nw = NWMIN;
-  if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, true>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stagger, pscale, per_wave, n0);
-  else hipLaunchKernelGGL((k_proj_fwd_bf16_v8<NT, NWMAX, false>), dim3((unsigned)G), dim3(nw * 64), 0, s, FWD_ARGS, stagger, pscale, per_wave, n0);
-}
-
-void launch_v8_rt(int nt, bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s, int Deq, bool f8,
-                  const float *pscale, int stagger, int n0) {
-  switch (nt) {
-    case 1: launch_v8<1>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 2: launch_v8<2>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 3: launch_v8<3>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 4: launch_v8<4>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 5: launch_v8<5>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 6: launch_v8<6>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 7: launch_v8<7>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    case 8: launch_v8<8>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-    default: launch_v8<9>(h, rows, nrows, Pout, s, Deq, f8, pscale, stagger, n0); break;
-  }
-}
-
 // row-list forward (k_proj_fwd_rows): column split / row tiles per workgroup by launch size and register budget
 template <int NT>
 void launch_fwd_rows(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_t *nrows_dev, int scatter, float *Pout,
@@ -1828,6 +1158,14 @@ void launch_fwd_rows(bprx_handle *h, const int32_t *rows, int64_t nrows, const i
 #undef ROWS_LAUNCH
 }
 
+// streaming (`nt`) feature loads when the table cannot stay in the 256-MiB Infinity Cache between the two passes of a step:
+// bf16 tables always (C2: 410 MB), fp8 tables from ~192 MB (C2's / c5small's 205-MB fp8 table stays: the backward pass
+// re-reads what the forward pass left in the cache, c2fp8 0.2091 vs 0.2152 ms/step with nt)
+inline bool fwd_nt_loads(const bprx_handle *h) {
+  const size_t bytes = (size_t)h->cfg.num_items * h->cfg.feat_dim * (h->cfg.feat_dtype == BPRX_F_FP8 ? 1 : 2);
+  return h->cfg.feat_dtype == BPRX_F_BF16 ? true : bytes > ((size_t)256 << 20);
+}
+
 // fp8 features, wide projection (NT >= 10): ONE pass on the block-scaled fp8 MFMA (k_proj_fwd_f8s), over the whole table or a
 // row list (nrows = the host-side bound of the list, the length is read on the device)
 template <int NT>
@@ -1841,7 +1179,7 @@ void launch_f8s(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_
   else G = (G + ncu - 1) / ncu * ncu;
   const size_t lds = (size_t)2 * NT * 2048 + 8 * 4096;
   // streaming (`nt`) loads when the table cannot stay in the 256-MiB Infinity Cache between the two passes of a step
-  const bool ntl = (size_t)h->cfg.num_items * h->cfg.feat_dim > ((size_t)192 << 20);
+  const bool ntl = fwd_nt_loads(h);
 #define F8S_LAUNCH(NTL_)                                                                                                  \
   do {                                                                                                                    \
     auto kfn = k_proj_fwd_f8s<NT, NTL_>;                                                                                  \
@@ -1854,105 +1192,69 @@ void launch_f8s(bprx_handle *h, const int32_t *rows, int64_t nrows, const int32_
 #undef F8S_LAUNCH
 }
 
+// v10 over the whole table, NT (<= 9) column tiles from column n0
 template <int NT>
-int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
-  constexpr int MTD = NT <= 9 ? 2 : 1;
-  // fwd_variant & 7: 0 = v1 (2 barriers per chunk, nothing overlapped), 1 = v1 with one row tile per wave,
-  //              2 = v6 (asm-pinned ping-pong pipeline, 4-wave workgroups of 128 items), 3 = v6 with one row tile per wave,
-  //              4 = v8 (default: one balanced workgroup per CU), 5 = v9 (A operand through LDS; experiment);
-  //              +8 = staggered chunk order; +16 / +32 / +64 = timing-only ablations of v1 / v6 (wrong results)
-  const int v = h->fwd_variant & 7, stg = (h->fwd_variant >> 3);
+void launch_v10(bprx_handle *h, int64_t nrows, float *Pout, hipStream_t s, int n0) {
+  constexpr int NWMAX = 8, NWMIN = 5;
   const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
   const int Deq = f8 ? h->cfg.feat_dim / 2 : h->cfg.feat_dim;
   const float *pscale = h->qs + 1;
-  const int MT = (v == 1 || v == 3) ? 1 : MTD;
-  dim3 grid((unsigned)((nrows + 4 * MT * 16 - 1) / (4 * MT * 16)));
-  // the pipelined kernel only where the build verified it spill-free (build.py), and D must hold an even chunk count
-  const bool pipe = !f8 && (v == 2 || v == 3 || v == 4) && Deq % 256 == 0 && bprx_variant_safe(6, NT, MT, 0);
-  if constexpr (NT == 5) {
-    static const int abl = getenv("BPRX_FWD_ABL") ? atoi(getenv("BPRX_FWD_ABL")) : 0;
-    if (pipe && MT != 1 && abl) {
-      switch (abl) {
-        case 1: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 2: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 2>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 3: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 3>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 4: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 4>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 6: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 6>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 7: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 7>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 14: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 14>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        case 15: hipLaunchKernelGGL((k_proj_fwd_bf16_v6<5, 2, 15>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale); return 0;
-        default: break;
+  const int64_t T = (nrows + 15) / 16;
+  const int ncu = h->num_cu > 0 ? h->num_cu : 256;
+  int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
+  if (G < ncu) G = T < ncu ? T : ncu;
+  else G = (G + ncu - 1) / ncu * ncu;
+  const int tpw_max = (int)((T + G - 1) / G);
+  const int per_wave = tpw_max > NWMAX ? 2 : 1;
+  int nw = (tpw_max + per_wave - 1) / per_wave;
+  if (nw < NWMIN) nw = NWMIN;
+  const size_t lds = (size_t)2 * NT * 16 * 288 + (size_t)nw * 2 * 16 * 288;
+  const bool ntl = fwd_nt_loads(h);
+#define V10_LAUNCH(F8_, NTL_)                                                                                             \
+  do {                                                                                                                    \
+    auto kfn = k_proj_fwd_bf16_v10<NT, F8_, NTL_>;                                                                        \
+    (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, (const uint16_t *)h->Ft, (int)nrows, Deq,            \
+                       (const uint16_t *)h->Et, Pout, h->PS, pscale, 0, per_wave, n0);                                     \
+  } while (0)
+  if (f8) { if (ntl) V10_LAUNCH(true, true); else V10_LAUNCH(true, false); }
+  else { if (ntl) V10_LAUNCH(false, true); else V10_LAUNCH(false, false); }
+#undef V10_LAUNCH
+}
+
+// P = F.[E|Bp] over the whole table.  BPRX_FWD_VARIANT=0: the plain kernel (k_proj_fwd_bf16: two barriers per chunk, nothing
+// overlapped) -- the reference every streaming kernel is tested against, and the fallback for odd widths.
+//   shape                                           kernel                              covered by
+//   <= 9 column tiles (d <= 143), bf16 or fp8       k_proj_fwd_bf16_v10                 test_gpu_variants::test_lds_staged_forward...
+//   >= 10 tiles, fp8 (configs[4]: d = 256)          k_proj_fwd_f8s (scaled fp8 MFMA)    test_gpu_variants::test_wide_projection...
+//   >= 10 tiles, bf16 (or BPRX_F8S=0)               v10 in right-aligned passes of 9    test_gpu_variants::test_wide_projection...
+//   feat_dim not a multiple of 256 (512 for fp8)    k_proj_fwd_bf16 (plain)             test_gpu_parity (D = 128 / 384 shapes)
+template <int NT>
+int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pout, hipStream_t s) {
+  constexpr int MTD = NT <= 9 ? 2 : 1;
+  const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
+  const int Deq = f8 ? h->cfg.feat_dim / 2 : h->cfg.feat_dim;
+  const float *pscale = h->qs + 1;
+  const bool plain = h->fwd_variant == 0 || Deq % 256 != 0 || rows;
+  if (!plain) {
+    if constexpr (NT >= 10) {
+      static const int f8s_on = getenv("BPRX_F8S") ? atoi(getenv("BPRX_F8S")) : 1;   // 0: column-range passes (A/B, tests)
+      if (f8 && f8s_on && h->EtS && h->cfg.feat_dim % 256 == 0) {
+        launch_f8s<NT>(h, nullptr, nrows, nullptr, 0, Pout, s, 1);
+        return 0;
       }
-    }
-  }
-  if constexpr (NT <= 9) {
-    if (v == 5 && Deq % 256 == 0) {                      // v9: A operand through LDS, contiguous loads of the tiled F
-      launch_v9<NT>(h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, 0);
+      // column ranges of nine tiles, the last one right-aligned: ranges may overlap by some tiles, which are then computed and
+      // stored twice, identically (F is read once per pass: two passes at d = 256)
+      for (int c0 = 0; c0 < NT; c0 += 9) launch_v10<9>(h, nrows, Pout, s, (c0 + 9 <= NT ? c0 : NT - 9) * 16);
+      return 0;
+    } else {
+      launch_v10<NT>(h, nrows, Pout, s, 0);
       return 0;
     }
   }
-  if constexpr (NT >= 10) {
-    // fp8 features, wide projection: ONE pass on the block-scaled fp8 MFMA (k_proj_fwd_f8s); BPRX_F8S=0 keeps the
-    // column-range passes of v8 for A/B measurements
-    const int f8s_on = getenv("BPRX_F8S") ? atoi(getenv("BPRX_F8S")) : 1;
-    if (f8 && v == 4 && f8s_on && h->EtS && h->cfg.feat_dim % 256 == 0) {
-      launch_f8s<NT>(h, nullptr, nrows, nullptr, 0, Pout, s, stg & 1);
-      return 0;
-    }
-  }
-  if constexpr (NT <= 9) {
-    // v10 (A through a wave-private LDS image, contiguous loads, `nt`): the default for bf16 tables up to nine column tiles
-    // -- C2: 76.7-80.2 us against v8's 83.4-87.2 us on the same boxes; with streaming (`nt`) loads 76.8-77.2 us and the
-    // whole step 0.2596 -> 0.2436 ms; c4 shard (nine tiles): 116.5 us against v8's 118.8-125.7 us, step 0.3587 -> 0.3511.
-    // Not for fp8 tables (c2fp8: 45.0 vs 41.7 us).  BPRX_FWD_LDS=0 keeps v8; variant 6 / 14 forces v10 (+ staggered chunks).
-    const bool lds_default = v == 4 && !f8 && NT <= 9 && !(getenv("BPRX_FWD_LDS") && atoi(getenv("BPRX_FWD_LDS")) == 0);
-    const int stg10 = v == 6 ? (stg & 1) : 0;
-    if ((v == 6 || lds_default) && Deq % 256 == 0 && !rows) {
-      constexpr int NWMAX = 8, NWMIN = 5;
-      const int64_t T = (nrows + 15) / 16;
-      const int ncu = h->num_cu > 0 ? h->num_cu : 256;
-      int64_t G = (T + 2 * NWMAX - 1) / (2 * NWMAX);
-      if (G < ncu) G = T < ncu ? T : ncu;
-      else G = (G + ncu - 1) / ncu * ncu;
-      const int tpw_max = (int)((T + G - 1) / G);
-      const int per_wave = tpw_max > NWMAX ? 2 : 1;
-      int nw = (tpw_max + per_wave - 1) / per_wave;
-      if (nw < NWMIN) nw = NWMIN;
-      const size_t lds = (size_t)2 * NT * 16 * 288 + (size_t)nw * 2 * 16 * 288;
-      if (f8) {
-        auto kfn = k_proj_fwd_bf16_v10<NT, true>;
-        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, (const uint16_t *)h->Ft, (int)nrows, Deq,
-                           (const uint16_t *)h->Et, Pout, h->PS, pscale, stg10, per_wave);
-      } else {
-        auto kfn = k_proj_fwd_bf16_v10<NT, false>;
-        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, (const uint16_t *)h->Ft, (int)nrows, Deq,
-                           (const uint16_t *)h->Et, Pout, h->PS, pscale, stg10, per_wave);
-      }
-      return 0;
-    }
-  }
-  if (v == 4 && Deq % 256 == 0) {
-    // v8 (one balanced workgroup per CU).  Projections wider than 9 column tiles (d > 143) are covered by two launches
-    // over column ranges (F is read twice: still less time than one pass of the plain kernel).
-    // Column ranges of the widest spill-free width (<= 9 tiles; normally the whole projection in one launch), the last
-    // one right-aligned: ranges may overlap by some tiles, which are then computed and stored twice, identically.
-    int wmax = NT < 9 ? NT : 9;
-    while (wmax >= 1 && !bprx_variant_safe(8, wmax, 8, f8 ? 1 : 0)) --wmax;
-    if (wmax >= (NT < 5 ? NT : 5)) {
-      for (int c0 = 0; c0 < NT; c0 += wmax) {
-        const int start = c0 + wmax <= NT ? c0 : NT - wmax;
-        launch_v8_rt(wmax, h, rows, nrows, Pout, s, Deq, f8, pscale, stg & 1, start * 16);
-      }
-      return 0;
-    }
-  }
-  if (pipe && MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, 1>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale);
-  else if (pipe) hipLaunchKernelGGL((k_proj_fwd_bf16_v6<NT, MTD>), grid, dim3(256), 0, s, FWD_ARGS, stg & 15, pscale);
-  else if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, true>), grid, dim3(256), 0, s, FWD_ARGS, stg & 1, pscale);
-  else if (MT == 1) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, 1, false>), grid, dim3(256), 0, s, FWD_ARGS, stg, pscale);
-  else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, false>), grid, dim3(256), 0, s, FWD_ARGS, stg, pscale);
+  dim3 grid((unsigned)((nrows + 4 * MTD * 16 - 1) / (4 * MTD * 16)));
+  if (f8) hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, true>), grid, dim3(256), 0, s, FWD_ARGS, 0, pscale);
+  else hipLaunchKernelGGL((k_proj_fwd_bf16<NT, MTD, false>), grid, dim3(256), 0, s, FWD_ARGS, 0, pscale);
   return 0;
 }
 
@@ -1988,68 +1290,29 @@ int launch_bwd_rows(bprx_handle *h, int64_t bound, hipStream_t s) {
   return 0;
 }
 
+// dE|dBp slabs = F^T W over the whole table: k_proj_bwd_bf16_v3 (W as bf16, conflict-free LDS image for the transpose reads).
+//   shape                                        instantiation                                      why
+//   bf16, <= 9 column tiles, D % 256 == 0        8 waves (256 columns), 3 tiles in flight           C2 / c4 shard: HBM-bound, deepest prefetch
+//   fp8, or > 9 column tiles                     8 waves, 2 tiles in flight, double-buffered LDS    MFMA-paced: one barrier per tile (c5, c2fp8)
+//   D % 256 != 0 (bf16)                          4 waves (128 columns), 2 tiles in flight           small / odd feature widths
 template <int NT>
 int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   const int D = h->cfg.feat_dim, I = h->cfg.num_items;
-  // bwd_variant: 0 = v1 (fp32 W, no prefetch); 8 = v3 (bf16 W, conflict-free LDS image, next tile prefetched),
-  //              9 = v3 with 64-item tiles; +2 = 8 waves / 256 columns per workgroup; +4 = descending item order
-  const int desc = (h->bwd_variant >> 2) & 1;
-  if (h->bwd_variant >= 8) {
-    const int bt3 = (h->bwd_variant & 1) ? 64 : 32;
-    int rps3 = (I + h->SK - 1) / h->SK;
-    rps3 = (rps3 + bt3 - 1) / bt3 * bt3;
-    const size_t n4 = (size_t)I * h->PS / 4;
-    if (!h->item_mode)   // k_item_seg has already written Wb (bf16) itself
-      hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
-    // bwd_variant & 2: 8 waves / 256 columns per workgroup (needs D % 256 == 0); bits 4-5: tiles in flight - 1
-    const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
-    const bool w8 = ((h->bwd_variant & 2) && D % 256 == 0) || f8;   // fp8: a 256-column tile row is one 256-B block row
-    const int pd = ((h->bwd_variant >> 4) & 3) + 1;
-    const int xmap = (h->bwd_variant & 64) ? 0 : 1;   // +64: plain blockIdx mapping (A/B)
-    dim3 g3(D / (w8 ? 256 : 128), h->SK);
-    // double-buffered LDS image (one barrier per tile) for the MFMA-paced shapes: fp8 tables and projections wider than nine
-    // column tiles, two tiles in flight; BPRX_BWD_DB = 0 / 1 forces it off / on wherever it is instantiated
-    bool db = (f8 || NT > 9) && pd == 2 && bt3 == 32 && w8;
-    if (const char *e = getenv("BPRX_BWD_DB")) db = atoi(e) != 0 && pd == 2 && bt3 == 32 && w8;
-#define BWD3_ARGS (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, desc, xmap, (const int32_t *)nullptr, \
+  int rps3 = (I + h->SK - 1) / h->SK;
+  rps3 = (rps3 + 31) / 32 * 32;
+  const size_t n4 = (size_t)I * h->PS / 4;
+  if (!h->item_mode)   // k_item_seg has already written Wb (bf16) itself
+    hipLaunchKernelGGL(k_cast_W, dim3(1024), dim3(256), 0, s, h->W, (uint16_t *)h->Wb, n4);
+  const bool f8 = h->cfg.feat_dtype == BPRX_F_FP8;
+  const bool w8 = D % 256 == 0 || f8;                   // fp8: a 256-column tile row is one 256-B block row
+  dim3 g3(D / (w8 ? 256 : 128), h->SK);
+#define BWD3_ARGS (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, 0, 1, (const int32_t *)nullptr, \
                   (const int32_t *)nullptr, (const float *)nullptr
-#define BWD3_LAUNCH(BTV_, NW_, PD_)                                                                                      \
-  do {                                                                                                                   \
-    if constexpr (NW_ == 8 && PD_ == 2 && BTV_ == 32) {                                                                  \
-      if (db) {                                                                                                          \
-        if (f8) launch_bwd3<NT, 32, 8, 2, true, false, 2>(g3, s, BWD3_ARGS);                                             \
-        else launch_bwd3<NT, 32, 8, 2, false, false, 2>(g3, s, BWD3_ARGS);                                               \
-        break;                                                                                                           \
-      }                                                                                                                  \
-    }                                                                                                                    \
-    if constexpr (NW_ == 8) {                                                                                            \
-      if (f8) {                                                                                                          \
-        launch_bwd3<NT, BTV_, 8, PD_, true, false, 1>(g3, s, BWD3_ARGS);                                                 \
-        break;                                                                                                           \
-      }                                                                                                                  \
-    }                                                                                                                    \
-    launch_bwd3<NT, BTV_, NW_, PD_, false, false, 1>(g3, s, BWD3_ARGS);                                                  \
-  } while (0)
-#define BWD3_PD(BTV_, NW_)                                        \
-  switch (pd) {                                                   \
-    case 1: BWD3_LAUNCH(BTV_, NW_, 1); break;                     \
-    case 2: BWD3_LAUNCH(BTV_, NW_, 2); break;                     \
-    case 3: BWD3_LAUNCH(BTV_, NW_, 3); break;                     \
-    default: BWD3_LAUNCH(BTV_, NW_, 4); break;                    \
-  }
-    if (bt3 == 32 && w8) { BWD3_PD(32, 8) }
-    else if (bt3 == 32) { BWD3_PD(32, 4) }
-    else if (w8) { BWD3_LAUNCH(64, 8, 1); }
-    else { BWD3_LAUNCH(64, 4, 1); }
-#undef BWD3_PD
-#undef BWD3_LAUNCH
+  if (f8) launch_bwd3<NT, 32, 8, 2, true, false, 2>(g3, s, BWD3_ARGS);
+  else if (w8 && NT > 9) launch_bwd3<NT, 32, 8, 2, false, false, 2>(g3, s, BWD3_ARGS);
+  else if (w8) launch_bwd3<NT, 32, 8, 3, false, false, 1>(g3, s, BWD3_ARGS);
+  else launch_bwd3<NT, 32, 4, 2, false, false, 1>(g3, s, BWD3_ARGS);
 #undef BWD3_ARGS
-    return 0;
-  }
-  int rps = (I + h->SK - 1) / h->SK;
-  rps = (rps + BT - 1) / BT * BT;
-  dim3 grid(D / 128, h->SK);
-  hipLaunchKernelGGL((k_proj_bwd_bf16<NT>), grid, dim3(256), 0, s, (const uint16_t *)h->Ft, I, D, h->W, h->PS, h->part, rps);
   return 0;
 }
 
@@ -2149,14 +1412,11 @@ int bprx_launch_proj_fwd(bprx_handle *h, const int32_t *rows, int64_t nrows, con
 #undef CALL
     BPRX_LAUNCH_CHECK(h, "k_proj_fwd_bf16");
   } else {
-    static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 2;
-    if (f32_tile >= 2 && h->cfg.feat_dim % 16 == 0) {     // (2, the default: fp64 matrix instruction; 1: vector-ALU tiles; 0: first form)
+    // fp32 features (the reference-precision path, fp64 accumulation): the fp64 matrix instruction where D allows, the plain
+    // wave-per-row kernel otherwise
+    if (h->cfg.feat_dim % 16 == 0) {
       dim3 grid((unsigned)((nrows + 15) / 16), (unsigned)((h->cfg.embed_d + 1 + 15) / 16));
       hipLaunchKernelGGL(k_proj_fwd_f32_mfma, grid, dim3(1024), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
-                         h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
-    } else if (f32_tile && h->cfg.feat_dim % 4 == 0) {
-      dim3 grid((unsigned)((nrows + F32_RT - 1) / F32_RT), (unsigned)((h->cfg.embed_d + 1 + 31) / 32));
-      hipLaunchKernelGGL(k_proj_fwd_f32_tile, grid, dim3(F32_NSL * 32), 0, s, (const float *)h->t.F, rows, (int)nrows, nrows_dev, scatter,
                          h->cfg.num_items, h->cfg.feat_dim, h->t.E, h->t.Bp, h->cfg.embed_d, Pout, h->PS, h->errflag);
     } else {
       dim3 grid((unsigned)((nrows + 3) / 4));
@@ -2202,14 +1462,9 @@ int bprx_launch_proj_bwd(bprx_handle *h, int64_t B, hipStream_t s) {
   } else {
     {
       BprxProfScope ps(h, BPRX_PHASE_PROJ_BWD, s);
-      static const int f32_tile = getenv("BPRX_F32_TILE") ? atoi(getenv("BPRX_F32_TILE")) : 2;
-      // (the tiled forms split the listed rows over the lane groups / waves of a block: for a row LIST; the whole-table sum
-      //  keeps one block per k)
-      // (the fp64-matrix form of the backward sum is no faster than the vector-ALU tiles here -- 19 vs 17 us: BPRX_F32_TILE=3)
-      if (f32_tile >= 3 && h->list_mode && D % 16 == 0)
-        hipLaunchKernelGGL(k_proj_bwd_f32_mfma, dim3(D / 16, (unsigned)((d + 1 + 15) / 16)), dim3(256), 0, s, (const float *)h->t.F,
-                           (int)bound, D, h->W, d, h->PS, h->dEp, (const int32_t *)h->ilist, (const int32_t *)h->list_cur);
-      else if (f32_tile && h->list_mode && D % F32_KV == 0)
+      // a row LIST is split over the lane groups of a block (vector-ALU tiles; the fp64-matrix form of this sum was no faster:
+      // 19 vs 17 us, removed); the whole-table sum keeps one block per k
+      if (h->list_mode && D % F32_KV == 0)
         hipLaunchKernelGGL(k_proj_bwd_f32_tile, dim3(D / F32_KV, (unsigned)((d + 1 + 31) / 32)), dim3(F32_NRS * 32), 0, s, (const float *)h->t.F,
                            (int)bound, D, h->W, d, h->PS, h->dEp, (const int32_t *)h->ilist, (const int32_t *)h->list_cur);
       else

@@ -2016,7 +2016,7 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
   const bool bf = h->cfg.feat_dtype != BPRX_F_FP32;     // bf16 W image (bf16 and fp8 features)
   // dense form with fp32 features (or the fp32-W backward variants): W is consumed in place and cleared here, at the
   // next step; list mode returns its rows to zero itself (k_cast_W_rows) and only needs the memset after such a step
-  const bool leaves_dirty = a.d && !h->list_mode && (!bf || (!h->item_mode && h->bwd_variant < 8));
+  const bool leaves_dirty = a.d && !h->list_mode && !bf;
   if (leaves_dirty || (a.d && h->W_dirty))
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   h->W_dirty = leaves_dirty;

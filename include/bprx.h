@@ -273,13 +273,6 @@ BPRX_API int bprx_eval_counts(bprx_handle *h, int32_t u0, int32_t u1, const floa
 BPRX_API int bprx_eval_finish(bprx_handle *h, int32_t u0, int32_t u1, int32_t items_total, const int64_t *eval_ptr,
                               const float *sp, const int32_t *counts, int32_t K, double *out, void *stream);
 
-/* Build-time table of the software-pipelined forward-projection instantiations that hipcc compiled free of scratch,
-   spills and stray AGPR use (only those are ever launched; every other shape falls back to the plain kernel).
-   ver 6 / 8 = pipelined kernel generation, nt = column tiles, mt = row tiles per wave (ver 6) or 8 (ver 8),
-   rem = ablation id (ver 6) / fp8 flag (ver 8).  Returns 1 / 0.  For the test-suite, which runs every listed
-   instantiation against the plain kernel. */
-BPRX_API int bprx_kernel_variant_safe(int ver, int nt, int mt, int rem);
-
 /* Evaluator.store_recommendation on the device (Evaluator.py:225-239) for users [u0,u1): the train items of each user are
    overwritten with -inf IN `scores` (the output of bprx_score_block for the same range; the reference does the same to its
    score matrix, :233) and the K (<= 1024) largest remaining scores are returned best first: idx int32 [(u1-u0), K] (-1 past
