@@ -123,7 +123,6 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       if (cfg->feat_dtype == BPRX_F_FP8 && PS / 16 <= 9) h->SK *= 2;
     }
     if (h->SK > 64) h->SK = 64;
-    if (const char *e = getenv("BPRX_SK")) h->SK = atoi(e);
     if (h->SK < 1) h->SK = 1;
     if (h->SK > 256) h->SK = 256;
     // BPRX_FWD_VARIANT=0: the plain forward kernel (the reference the streaming kernels are tested against); anything else:
@@ -225,9 +224,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   }
   // exclusive-row fast path: sgd only (adam sweeps every row anyway); not with exported user gradients
   h->fast_rows = (cfg->optimizer == BPRX_OPT_SGD && !(cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD)) ? 1 : 0;   // per side: make_args
-  if (const char *e = getenv("BPRX_FAST_ROWS")) h->fast_rows = h->fast_rows && atoi(e);
-  if (h->fast_rows && !(cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) &&
-      !(getenv("BPRX_SHARED_LIST") && atoi(getenv("BPRX_SHARED_LIST")) == 0)) {
+  if (h->fast_rows && !(cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD))) {
     if (dalloc_zero(&h->slist, (size_t)3 * MB) != hipSuccess || dalloc_zero(&h->slist_n, (size_t)2) != hipSuccess) {
       snprintf(g_create_err, sizeof(g_create_err), "shared-row list allocation failed");
       free_scratch(h);
@@ -247,8 +244,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
   //   1  the sparse optimizer pass beside the backward projection: SLOWER (0.385 vs 0.363 ms/step; both are
   //      bandwidth-bound and interfere: proj_bwd 93 -> 144 us, apply 35 -> 64 us)
   //   (2, removed: the segment-mode index pass beside the forward projection.  Round 2's pass, 130 K memory-side count atomics:
-  //      0.2599 vs 0.2600 ms, both kernels stretched; round 3's k_index_seg, LDS counting: 0.238 vs 0.229 ms -- its 1024-thread
-  //      workgroups are only placed as the projection's one-workgroup-per-CU grid drains, and the join then waits for them)
+  //      0.2599 vs 0.2600 ms, both kernels stretched; round 3's k_index_seg, LDS counting: 0.238 vs 0.229 ms on a plain side
+  //      stream -- its workgroups share every CU's memory pipeline with the projection's streaming loads and take 84 us instead
+  //      of 19 -- and 0.250 / 0.246 vs 0.224 ms on a stream whose CU mask confines it to 16 / 32 CUs: with few owner workgroups
+  //      each of them matches 16x / 8x more of the scanned values and the rare-match path of the scan becomes its bulk)
   //   4  lazy Adam's catch-up (ALU-bound: correctly rounded sqrt / divide per replayed element and step) beside the
   //      HBM-bound forward projection of a streaming step: adam_tf23 0.330 -> 0.317 ms/step.  The default with adam_tf23.
   {
@@ -654,7 +653,7 @@ extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *o
     if ((rc = bprx_launch_proj_fwd(h, nullptr, h->cfg.num_items, nullptr, 0, h->P, s))) return rc;
     h->p_valid = true;
   }
-  if (h->cfg.embed_k % 2 == 0 && h->cfg.embed_d % 2 == 0 && !getenv("BPRX_NAIVE_SCORE_BLOCK"))
+  if (h->cfg.embed_k % 2 == 0 && h->cfg.embed_d % 2 == 0)
     return bprx_launch_score_gemm(h, u0, u1, out, s);          // fp32 MFMA GEMM (K step 2)
   return bprx_launch_score_block(h, u0, u1, out, s);
 }

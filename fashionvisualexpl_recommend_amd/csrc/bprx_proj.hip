@@ -1134,10 +1134,8 @@ void launch_fwd_rows(bprx_handle *h, const int32_t *rows, int64_t nrows, const i
   int mt = 1;
   if (NT <= 5 && tiles > 8 * (int64_t)ncu) mt = 4;
   else if (NT <= 9 && tiles > 2 * (int64_t)ncu) mt = 2;
-  if (const char *e = getenv("BPRX_ROWS_MT")) { const int v = atoi(e); if (v == 1 || (v == 2 && NT <= 9) || (v == 4 && NT <= 5)) mt = v; }
   // tiny launches (row tiles x column tiles fit the chip twice): one column tile per workgroup, 16 waves split K
   bool split = NT > 1 && tiles * NT <= 2 * (int64_t)ncu;
-  if (const char *e = getenv("BPRX_ROWS_SPLIT")) split = NT > 1 && atoi(e) != 0;
 #define ROWS_LAUNCH(NTW_, MT_, NW_, F8_, GY_)                                                                            \
   do {                                                                                                                   \
     auto kfn = k_proj_fwd_rows<NTW_, MT_, NW_, F8_>;                                                                     \

@@ -1570,10 +1570,8 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   else { a.uG = h->t.Gu; a.uT = h->t.Tu; a.usG = a.k; a.usT = a.d; }
   // shared-row list: both sides on the exclusive-row fast path (sgd, atomic staging, no exported gradients)
   a.use_list = (h->slist && a.fastU && a.fastI) ? 1 : 0;
-  static const int reg_items_env = getenv("BPRX_REG_ITEMS") ? atoi(getenv("BPRX_REG_ITEMS")) : 1;
-  a.reg_items = reg_items_env;
-  static const int wg_combine_env = getenv("BPRX_WG_COMBINE") ? atoi(getenv("BPRX_WG_COMBINE")) : 1;
-  a.wg_combine = wg_combine_env;
+  a.reg_items = 1;
+  a.wg_combine = 1;
   a.slist = h->slist;
   a.slist_n = h->slist ? h->slist_n + h->slist_slot : nullptr;
   return a;
@@ -2178,7 +2176,7 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   // fp8 features: the slabs hold (F*feat_scale)^T W; an all-reduced dEp was already rescaled by k_reduce_parts
   const float gscale = (part && h->cfg.feat_dtype == BPRX_F_FP8) ? 1.0f / h->cfg.feat_scale : 1.0f;
   // bf16 features: this kernel writes the next step's [E|Bp]^T images (fp8 images need the global max first: k_cast_Et8)
-  const bool images = h->cfg.feat_dtype == BPRX_F_BF16 && !getenv("BPRX_NO_ET_FUSE");
+  const bool images = h->cfg.feat_dtype == BPRX_F_BF16;
   const bool lm = h->list_mode != 0;
   const int64_t bound = lm ? h->list_bound : 0;
   hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,

@@ -3,8 +3,8 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-SETTINGS=("BPRX_LIST_MODE=0" "BPRX_LIST_MODE=2" "BPRX_ITEM_MODE=0" "BPRX_ITEM_MODE=2" "BPRX_ADAM_LAZY=0" "BPRX_GRAPH=1" "BPRX_GRAPH=2" "BPRX_SHARED_LIST=0" "BPRX_SIDE_STREAM=0" "BPRX_SIDE_STREAM=5" "BPRX_FAST_ROWS=0")
-if [ -n "${MATRIX_ONLY:-}" ]; then SETTINGS=("BPRX_LIST_MODE=0" "BPRX_LIST_MODE=2" "BPRX_ITEM_MODE=0" "BPRX_ITEM_MODE=2" "BPRX_ADAM_LAZY=0" "BPRX_GRAPH=1" "BPRX_GRAPH=2" "BPRX_SHARED_LIST=0" "BPRX_SIDE_STREAM=0" "BPRX_SIDE_STREAM=5" "BPRX_FAST_ROWS=0")
+SETTINGS=("BPRX_LIST_MODE=0" "BPRX_LIST_MODE=2" "BPRX_ITEM_MODE=0" "BPRX_ITEM_MODE=2" "BPRX_ADAM_LAZY=0" "BPRX_GRAPH=1" "BPRX_GRAPH=2" "BPRX_SIDE_STREAM=0" "BPRX_SIDE_STREAM=5")
+if [ -n "${MATRIX_ONLY:-}" ]; then SETTINGS=("BPRX_LIST_MODE=0" "BPRX_LIST_MODE=2" "BPRX_ITEM_MODE=0" "BPRX_ITEM_MODE=2" "BPRX_ADAM_LAZY=0" "BPRX_GRAPH=1" "BPRX_GRAPH=2" "BPRX_SIDE_STREAM=0" "BPRX_SIDE_STREAM=5")
 for envs in "${SETTINGS[@]}"; do
   tag=$(echo "$envs" | tr ' =' '__')
   ( for kv in $envs; do export "$kv"; done
