@@ -42,7 +42,7 @@ static bool graph_sig_eq(const bprx_handle::GraphSig &a, const bprx_handle::Grap
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_cnt, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->uslot_of, h->udone, h->uold, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_cnt, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->uslot_of, h->ulist, h->uold, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -165,10 +165,10 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       h->seg_lead_cap = (int64_t)(I + 8192 + 4 * 1024 + 2 * MB / 64 + 64 + 64);
       h->seg_ent_cap = (int64_t)(6 * MB + 64 * 1024 + 2048);
       bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_cnt, I) == hipSuccess &&
-                 dalloc_zero(&h->seg_ptr, I) == hipSuccess && dalloc_zero(&h->seg_cursor, (size_t)4) == hipSuccess &&
+                 dalloc_zero(&h->seg_ptr, I) == hipSuccess && dalloc_zero(&h->seg_cursor, (size_t)6) == hipSuccess &&
                  dalloc_zero((int4 **)&h->seg_lead, (size_t)h->seg_lead_cap) == hipSuccess &&
                  dalloc_zero(&h->hot_done, I) == hipSuccess && dalloc_zero((int2 **)&h->seg_ent, (size_t)h->seg_ent_cap) == hipSuccess &&
-                 dalloc_zero(&h->uslot_of, U) == hipSuccess && dalloc_zero(&h->udone, MB) == hipSuccess &&
+                 dalloc_zero(&h->uslot_of, U) == hipSuccess && dalloc_zero(&h->ulist, MB) == hipSuccess &&
                  dalloc_zero(&h->uold, MB * (k + d)) == hipSuccess;
       if (!ok2) {
         snprintf(g_create_err, sizeof(g_create_err), "segment scratch allocation failed");

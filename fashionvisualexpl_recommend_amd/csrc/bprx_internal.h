@@ -62,19 +62,19 @@ struct bprx_handle {
   int32_t *seg_rank;              // [2 * max_batch] rank of occurrence (role*B + b) among its item's occurrences
   int32_t *seg_cnt;               // [I] occurrences of the item in this batch (rewritten for every item by each index pass)
   int32_t *seg_ptr;               // [I] start of the item's segment in seg_ent
-  int32_t *seg_cursor;            // [4] two (entries, listed chunks) cursor pairs used by alternate steps: an index pass
-                                  //     clears the pair of the NEXT step
+  int32_t *seg_cursor;            // [6] two (overflow entries, overflow chunks, listed users) cursor triples used by alternate
+                                  //     steps: an index pass clears the triple of the NEXT step
   int seg_slot;                   // cursor pair of the next segment-mode step
   int seg_cur_slot;               // cursor pair of the step in flight
   void *seg_lead;                 // int4 [seg_lead_cap] {item, first entry, entries of the chunk, entries of the item}: k_item_seg's work list
   int64_t seg_lead_cap;
   int seg_lead_over;              // this step: slots of the owners' regions (the overflow list follows)
   int64_t seg_ent_cap;            // entries allocated in seg_ent
-  // user side of a segment-mode sgd step: the batch's users are finished inside k_triplet_seg (run-segmented sums in LDS;
-  // users whose occurrences span workgroups meet in the staging rows and the workgroup that arrives last finishes them), so
-  // there is no apply pass.  k_item_seg, which needs the PRE-update user rows afterwards, reads them from uold.
+  // user side of a segment-mode sgd step: k_triplet_seg sums the runs of equal users in LDS and adds the run sums to the staging
+  // rows; finishing lane groups at the front of k_item_seg's grid apply the totals (no apply launch).  k_item_seg's item groups,
+  // which need the PRE-update user rows, read them from uold (saved by the run that starts at the user's slot).
   int32_t *uslot_of;              // [U] batch position of the user's first run head = the user's slot (valid for users of the batch)
-  int32_t *udone;                 // [max_batch] occurrences of the slot's user that have been added (all-zero between steps)
+  int32_t *ulist;                 // [max_batch] the batch's users (first-run order): walked by k_item_seg's finishing groups
   float *uold;                    // [max_batch][k + d] pre-update [gamma_u | theta_u] of the slot's user
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [seg_ent_cap] 8-byte entries {user or user slot | role << 31, g_b}: the owners' regions (twice

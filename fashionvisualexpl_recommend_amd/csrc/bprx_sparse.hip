@@ -45,6 +45,9 @@ struct SparseArgs {
   const float *uG, *uT;      // PRE-update user rows as k_item_seg gathers them: the tables (key = user id), or the batch's
   int usG, usT;              //   uold rows (key = user slot; k_triplet_seg mode 0); row strides in floats
   int32_t *hot_done;         // [I]  finished chunks of a hot item (k_item_seg's last-finisher hand-off), all-zero between steps
+  // finishing lane groups of k_item_seg (segment-mode sgd): the batch's users (k_index_seg) and their number
+  const int32_t *ulist, *ulist_n;
+  int nfin;                  // workgroups at the front of k_item_seg's grid that finish users (0: none)
   // shared-row list (sgd fast path): the occurrence that marks a shared row first appends it (kind << 30 | row); the apply
   // pass then walks this list instead of every occurrence of the batch
   int32_t *slist, *slist_n;
@@ -1034,7 +1037,8 @@ __global__ __launch_bounds__(256) void k_score_block(SparseArgs a, int u0, int u
 // rows of its UNTOUCHED items (7 % of the rows at C2, instead of the whole 8-MB image).
 // User workgroups (blockIdx < nuser, sgd segment steps): one thread per triplet; the first lane of every run of equal users
 // inside a wave adds the run's length to cntU[u] (the reference's visiting order has ~20 triplets per user: 1 atomic in 20) and
-// the add that finds the count at zero names the user's slot for this batch: the batch position of that run head.
+// the add that finds the count at zero names the user's slot for this batch (the batch position of that run head) and appends
+// the user to the list of the batch's users, which the finishing lane groups of k_item_seg walk.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int IX_T = 1024;        // threads of an index workgroup
 constexpr int IX_RMAX = 8192;     // items an owner workgroup can own (LDS counters)
@@ -1049,9 +1053,9 @@ struct IndexSegArgs {
   // (Lc = R + IX_LPAD slots): the usual step takes no global atomic.  An owner whose entries do not fit (hot items) reserves
   // ALL of them behind the regions (ent_over + cursor), and chunks that do not fit go to the overflow list behind the regions.
   int Ce, Lc, ent_over, lead_over, lead_cap;
-  int32_t *cur, *cur_next;        // this step's overflow cursor pair (entries, listed chunks) and the next step's (cleared here)
+  int32_t *cur, *cur_next;        // this step's cursors (overflow entries, overflow chunks, listed users) and the next step's (cleared here)
   int4 *lead;
-  int32_t *cntU, *uslot_of;       // user side; nullptr: not wanted (the user gradients stay in the staging tables)
+  int32_t *cntU, *uslot_of, *ulist;   // user side; nullptr: not wanted (the user gradients stay in the staging tables)
   uint16_t *Wb;                   // bf16 W image (rows of untouched items are zeroed) or nullptr
   int PS;
   int aligned;                    // pos / neg are 16-byte aligned
@@ -1072,9 +1076,25 @@ __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
     const int hl = (hm & le) ? 63 - __clzll((long long)(hm & le)) : lane;                 // first lane of my run
     const unsigned long long stops = (hm | ~vm) & ~(hl == 63 ? ~0ull : ((2ull << hl) - 1ull));
     const int run_end = stops ? __ffsll((long long)stops) - 1 : 64;                       // first lane after my run
-    if (valid && lane == hl) {
-      const int old = atomicAdd(a.cntU + u, run_end - hl);
-      if (old == 0) a.uslot_of[u] = (int)b;
+    // the add that finds the count at zero names the user's slot and lists the user for the finishing pass (k_item_seg); the
+    // listed users of the WORKGROUP take their list positions with one cursor atomic (one per wave put 1 024 same-address
+    // returning atomics in a row: +11 us on this kernel)
+    __shared__ int u_wcnt[IX_T / 64], u_base;
+    int old = -1;
+    if (valid && lane == hl) old = atomicAdd(a.cntU + u, run_end - hl);
+    const bool firstrun = old == 0;
+    const unsigned long long fm = __ballot(firstrun);
+    if (lane == 0) u_wcnt[wv] = __popcll(fm);
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int q = 0; q < IX_T / 64; ++q) { const int c = u_wcnt[q]; u_wcnt[q] = t; t += c; }
+      u_base = t ? atomicAdd(a.cur + 2, t) : 0;
+    }
+    __syncthreads();
+    if (firstrun) {
+      a.uslot_of[u] = (int)b;
+      a.ulist[u_base + u_wcnt[wv] + __popcll(fm & (lane ? (~0ull >> (64 - lane)) : 0ull))] = u;   // (at most B users: the list holds max_batch)
     }
     return;
   }
@@ -1086,7 +1106,7 @@ __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
   const int lo = w * a.R;
   const int Rw = a.I - lo < a.R ? a.I - lo : a.R;                   // > 0: nown = ceil(I / R)
   for (int t = tid; t < Rw; t += IX_T) cnt[t] = 0;
-  if (w == 0 && tid == 0) { a.cur_next[0] = 0; a.cur_next[1] = 0; }
+  if (w == 0 && tid == 0) { a.cur_next[0] = 0; a.cur_next[1] = 0; a.cur_next[2] = 0; }
   __syncthreads();
   // My items as a SIGNED interval [Lb, Hb]: out-of-range indices are clamped like everywhere else (to item 0 / I-1; reported by
   // k_triplet_seg), so the first owner also takes everything below 0 and the last one everything above.  Four values are
@@ -1183,11 +1203,13 @@ __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
 // before -- and the USER side without a staging round trip: the per-occurrence user-row gradients of the workgroup's
 // TS_T / G consecutive triplets go to LDS, the runs of equal users inside the workgroup are summed there IN ORDER (one wave
 // per run, lane = column), and
-//   mode 0 (sgd): a run that holds ALL the batch's occurrences of its user (cntU[u], k_index_seg) finishes the user right
-//          here -- the pre-update row goes to uold[slot] for k_item_seg, the table row is updated in place; a user whose
-//          occurrences span workgroups (a run cut by a workgroup boundary, a user with several runs) meets in the staging
-//          row: atomic adds, then the occurrence counter udone[slot]; the workgroup that completes the count reads the
-//          total back where the atomics live and finishes the user.  No apply pass, no claim marks.
+//   mode 0 (sgd): every run sum is added to the user's staging row (runs of one user cut by a workgroup boundary, or several
+//          runs of a user, meet there), and the run that starts at the user's slot saves the pre-update row to uold[slot] for
+//          k_item_seg's gathers.  Nothing is waited for.  The totals are applied by a few finishing lane groups at the front of
+//          k_item_seg's grid (they walk the list of the batch's users built by k_index_seg): no apply launch, no claim marks.
+//          (A first version finished users inside this kernel -- occurrence counters and a last-arriver read-back of the
+//          totals: the waits for the atomics' acknowledgements and the counter round trips stretched every workgroup's tail,
+//          32.5 us against 26.7 us in mode 1.)
 //   mode 1 (adam_tf23, exported user gradients): the run sums are added to the staging rows and the user is marked.
 // In the reference's visiting order (runs of ~20 triplets) that is 2 atomic row adds per workgroup of 32 triplets instead of
 // one per wave or per triplet, and every sum inside a run is taken in batch order.
@@ -1197,7 +1219,6 @@ constexpr int TS_T = 512;
 struct SegUser {
   int mode;
   const int32_t *uslot_of;
-  int32_t *udone;
   float *uold;
 };
 
@@ -1206,7 +1227,7 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
                                                       const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
   constexpr int T = TS_T / G;                               // triplets per workgroup (<= 64)
   __shared__ __attribute__((aligned(16))) float rows[4096];  // [T][k + d], k + d <= 8 G
-  __shared__ int s_user[T], s_slot[T], s_tot[T];
+  __shared__ int s_user[T], s_slot[T];
   const int tl = threadIdx.x / G, lane = threadIdx.x % G;
   const int64_t b0 = (int64_t)blockIdx.x * T + tl;
   const bool valid = b0 < B;                                // (the surplus groups of the last workgroup run along: barriers)
@@ -1222,8 +1243,8 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
     const unsigned top = (unsigned)a.seg_cap - 1u;          // (never beyond the allocation, whatever the index state holds)
     spI = (int)((unsigned)spI < top ? (unsigned)spI : top); spJ = (int)((unsigned)spJ < top ? (unsigned)spJ : top);
   }
-  int slot = 0, tot = 0;
-  if (su.mode == 0) { slot = su.uslot_of[u]; tot = a.cntU[u]; }
+  int slot = 0;
+  if (su.mode == 0) slot = su.uslot_of[u];
   const int c4 = lane * 4;
   const bool hk = c4 < k, hd = c4 < d;
   const int ck = hk ? c4 : 0, cd = hd ? c4 : 0;
@@ -1274,7 +1295,7 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
                                                               g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w);
   if (hd) *reinterpret_cast<float4 *>(row + k + c4) = make_float4(g * (tq.x - tr.x) + r2 * tp.x, g * (tq.y - tr.y) + r2 * tp.y,
                                                                   g * (tq.z - tr.z) + r2 * tp.z, g * (tq.w - tr.w) + r2 * tp.w);
-  if (lane == 0) { s_user[tl] = valid ? u : -1 - tl; s_slot[tl] = slot; s_tot[tl] = tot; }
+  if (lane == 0) { s_user[tl] = valid ? u : -1 - tl; s_slot[tl] = slot; }
   __syncthreads();
   const int wl = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int myu = wl < T ? s_user[wl] : 0, pru = (wl > 0 && wl < T) ? s_user[wl - 1] : 0;
@@ -1288,7 +1309,6 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
     const int s1 = m ? __ffsll((long long)m) - 1 : T;
     const int uu = s_user[s0];
     if (uu < 0) continue;
-    const int seglen = s1 - s0;
     float acc[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
@@ -1306,37 +1326,17 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
       if (wl == 0) a.flagU[uu] = 1u;
       continue;
     }
-    const int sl = s_slot[s0], total = s_tot[s0];
-    float *const uo = su.uold + (size_t)sl * kd;
-    if (seglen == total) {                                  // the whole user is here: finish it (no atomics)
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        const int c = wl + 64 * x;
-        if (c < kd) { float *t = c < k ? tG + c : tT + (c - k); const float old = *t; uo[c] = old; *t = old - lr * acc[x]; }
-      }
-      if (wl == 0) a.cntU[uu] = 0;
-      continue;
-    }
+    // mode 0: the run's sum meets the user's other runs in the staging row (fire and forget: the totals are applied by the
+    // finishing lane groups of k_item_seg, after this kernel); the segment that starts at the user's slot -- the first run
+    // head of the user in the batch -- saves the PRE-update row for k_item_seg's gathers
 #pragma unroll
     for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) atomicAdd(c < k ? sG + c : sT + (c - k), acc[x]); }
-    // the adds execute at the memory side; the counter may move only once they have been performed (their acknowledgements)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int dn = 0;
-    if (wl == 0) dn = atomicAdd(su.udone + sl, seglen);
-    dn = __shfl(dn, 0, 64);
-    if (dn + seglen != total) continue;                     // somebody else completes this user
-    asm volatile("" ::: "memory");
+    const int sl = s_slot[s0];
+    if ((int64_t)blockIdx.x * T + s0 == (int64_t)sl) {
+      float *const uo = su.uold + (size_t)sl * kd;
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      const int c = wl + 64 * x;
-      if (c < kd) {
-        float *st = c < k ? sG + c : sT + (c - k), *t = c < k ? tG + c : tT + (c - k);
-        const float tsum = atomicAdd(st, 0.f);              // the total, read where the atomics live
-        *st = 0.f;                                          // staging back to all-zero
-        const float old = *t; uo[c] = old; *t = old - lr * tsum;
-      }
+      for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) uo[c] = c < k ? tG[c] : tT[c - k]; }
     }
-    if (wl == 0) { su.udone[sl] = 0; a.cntU[uu] = 0; }
   }
 }
 
@@ -1365,8 +1365,33 @@ struct AdamFuse { float *mGi, *vGi, *mBi, *vBi; int32_t *lastI; float b1, b2, ep
 template <int G, int ADAM>
 __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
                                                   float *__restrict__ Wf, uint16_t *__restrict__ Wb, float lr, AdamFuse af) {
-  const int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
+  if ((int)blockIdx.x < a.nfin) {
+    // ---- finishing lane groups (segment-mode sgd): the batch's users, whose gradient totals k_triplet_seg left in the staging
+    // rows, take their update here: table row -= lr * total, staging row and occurrence count back to zero.  (The item groups
+    // of this launch gather the PRE-update user rows from uold, not from the tables.)
+    const int n = a.ulist_n[0];
+    const int ngroups = a.nfin * (256 / G);
+    const int c4 = lane * 4;
+    for (int e = ((int)blockIdx.x * 256 + (int)threadIdx.x) / G; e < n; e += ngroups) {
+      const int u = clamp_quiet(a.ulist[e], a.U);
+      if (c4 < a.k) {
+        float *t = a.wGu + (size_t)u * a.k + c4, *g = a.dGu + (size_t)u * a.k + c4;
+        const float4 tv = ld4(t), gv = ld4(g);
+        *reinterpret_cast<float4 *>(t) = make_float4(tv.x - lr * gv.x, tv.y - lr * gv.y, tv.z - lr * gv.z, tv.w - lr * gv.w);
+        *reinterpret_cast<float4 *>(g) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (c4 < a.d) {
+        float *t = a.wTu + (size_t)u * a.d + c4, *g = a.dTu + (size_t)u * a.d + c4;
+        const float4 tv = ld4(t), gv = ld4(g);
+        *reinterpret_cast<float4 *>(t) = make_float4(tv.x - lr * gv.x, tv.y - lr * gv.y, tv.z - lr * gv.z, tv.w - lr * gv.w);
+        *reinterpret_cast<float4 *>(g) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (lane == 0) a.cntU[u] = 0;
+    }
+    return;
+  }
+  const int64_t e0 = ((int64_t)((int)blockIdx.x - a.nfin) * blockDim.x + threadIdx.x) / G;
   // one lane group per listed chunk (k_index_seg): an ordinary item is one chunk, a hot one is cut into chunks of SEG_CAP
   // (the owners' regions first -- unused slots hold no work -- then the overflow list, whose length is read on the device)
   if (e0 >= a.seg_lead_over) {
@@ -1561,7 +1586,9 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
   }
   a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
   a.seg_lead = (const int4 *)h->seg_lead; a.seg_lead_cap = (int)h->seg_lead_cap;
-  a.seg_nlead = h->seg_cursor ? h->seg_cursor + 2 * h->seg_cur_slot + 1 : nullptr;
+  a.seg_nlead = h->seg_cursor ? h->seg_cursor + 3 * h->seg_cur_slot + 1 : nullptr;
+  a.ulist = h->ulist; a.ulist_n = h->seg_cursor ? h->seg_cursor + 3 * h->seg_cur_slot + 2 : nullptr;
+  a.nfin = 0;
   a.seg_lead_over = h->seg_lead_over;
   a.seg_cap = (int)h->seg_ent_cap;
   // where k_item_seg finds the pre-update user rows: a segment-mode sgd step finishes its users inside k_triplet_seg and
@@ -1979,11 +2006,11 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
       BPRX_FAIL(h, BPRX_E_STATE, "index pass: segment buffers too small (I=%d, B=%lld)", a.I, (long long)B);
     h->seg_lead_over = x.lead_over;
     h->seg_cur_slot = h->seg_slot;                                               // the pair this step's kernels read
-    x.cur = h->seg_cursor + 2 * h->seg_slot; x.cur_next = h->seg_cursor + 2 * (h->seg_slot ^ 1);
+    x.cur = h->seg_cursor + 3 * h->seg_slot; x.cur_next = h->seg_cursor + 3 * (h->seg_slot ^ 1);
     h->seg_slot ^= 1;
     x.lead = (int4 *)h->seg_lead;
     const bool users = seg_finishes_users(h);
-    x.cntU = users ? h->cntU : nullptr; x.uslot_of = users ? h->uslot_of : nullptr;
+    x.cntU = users ? h->cntU : nullptr; x.uslot_of = users ? h->uslot_of : nullptr; x.ulist = users ? h->ulist : nullptr;
     const bool zw = a.d && h->cfg.feat_dtype != BPRX_F_FP32;                      // bf16 W image: rows of untouched items
     x.Wb = zw ? (uint16_t *)h->Wb : nullptr; x.PS = a.PS;
     x.aligned = (((uintptr_t)i | (uintptr_t)j) & 15) == 0;
@@ -2019,7 +2046,7 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
     BPRX_HIP(h, hipMemsetAsync(h->W, 0, (size_t)a.I * a.PS * sizeof(float), s));
   h->W_dirty = leaves_dirty;
   if (h->item_mode) {                                   // (segment mode implies the 16-B-per-lane layout: k % 4 == d % 4 == 0)
-    const SegUser su = {seg_finishes_users(h) ? 0 : 1, h->uslot_of, h->udone, h->uold};
+    const SegUser su = {seg_finishes_users(h) ? 0 : 1, h->uslot_of, h->uold};
     const int Gs = pick_group(a.k, a.d, true);
     const dim3 grid((unsigned)((B * Gs + TS_T - 1) / TS_T));
     switch (Gs) {
@@ -2046,7 +2073,12 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
   // (k_index_seg zeroed the bf16 rows of this batch's untouched items)
   // one lane group per chunk-list slot: the owners' regions (~one slot per item) + the overflow list (hot items' extra chunks)
   const int64_t bound = (int64_t)h->seg_lead_over + 2 * B / SEG_CAP + 64;
-  const dim3 grid = grid_for(bound, G);
+  // (the finishing workgroups stride over the batch's users -- a few thousand in the reference's visiting order, up to B for
+  //  i.i.d. batches: sized for a quarter of B, the surplus ones leave after one load)
+  int64_t nfin = B * G / 256 / 4;
+  nfin = nfin < 16 ? 16 : (nfin > 2048 ? 2048 : nfin);
+  a.nfin = seg_finishes_users(h) ? (int)nfin : 0;
+  const dim3 grid((unsigned)(grid_for(bound, G).x + a.nfin));
 #define LAUNCH_SEG(GG)                                                                                                   \
   do {                                                                                                                   \
     if (adam == 2) hipLaunchKernelGGL((k_item_seg<GG, 2>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
