@@ -375,7 +375,7 @@ def main():
         traffic, pmc, pmc_ok = None, {}, False
         list_mode_run = w["model"] == "vbpr" and 2 * B < w["I"]      # libbprx's per-step policy (touched-item list)
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")))
             pmc_ok = args.workload == "c2" and B == WORKLOADS["c2"]["B"] and args.optimizer == "sgd"
             if pmc_ok and dom in pmc:
                 traffic = pmc[dom]["hbm_bytes"]

@@ -92,7 +92,25 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
   u[b] = uu; i[b] = lst[n - epoch_ptr[lo]]; j[b] = jj;
 }
 
+// Sort keys of an epoch's user order: key[u] = 63 bits of philox(key = seed, ctr = (u, 0, 0xFFFFFFFF, epoch)) -- the third
+// counter word never collides with the negative draws (attempt numbers < 1024).  The epoch's order is the STABLE ascending
+// argsort of the keys (caller: a device radix sort); the CPU twin computes the same keys (oracle orc_epoch_keys).
+__global__ __launch_bounds__(256) void k_epoch_keys(uint32_t k0, uint32_t k1, uint32_t epoch, int U, int64_t *__restrict__ keys) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= U) return;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)u, 0u, 0xFFFFFFFFu, epoch, k0, k1, r);
+  keys[u] = (int64_t)((((unsigned long long)(r[1] & 0x7fffffffu)) << 32) | r[0]);
+}
+
 }  // namespace
+
+extern "C" int bprx_epoch_keys(uint64_t seed, uint32_t epoch, int32_t num_users, int64_t *keys, void *stream) {
+  if (!keys || num_users <= 0) return BPRX_E_INVALID;
+  hipLaunchKernelGGL(k_epoch_keys, dim3((unsigned)((num_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), epoch, num_users, keys);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}
 
 extern "C" int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
                                  const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items, uint64_t seed,

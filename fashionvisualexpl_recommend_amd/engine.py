@@ -360,20 +360,39 @@ class PhiloxSampler:
 
 class EpochWalkSampler(PhiloxSampler):
     """bprx_sample_epoch: the reference's visiting order as a device stream -- per epoch a fresh permutation of the users
-    (host NumPy RandomState(seed + epoch), 4 B per user uploaded once per epoch), every positive of every user exactly
-    once, consecutively; negatives by Philox rejection.  Batches are user-grouped like the reference's."""
+    (the stable argsort of per-user Philox keys, computed on the device), every positive of every user exactly once,
+    consecutively; negatives by Philox rejection.  Batches are user-grouped like the reference's."""
 
-    def _start_epoch(self, epoch):
+    def _prepare(self, epoch):
+        """Everything epoch `epoch` needs, ENQUEUED without a host synchronisation or an upload: the user order is the stable
+        argsort of per-user Philox keys (bprx_epoch_keys + a device radix sort; the CPU twin sorts the same keys), the prefix sums
+        of the list lengths in that order and the position -> slot map are device ops (repeat_interleave with a known output
+        size).  Prepared ONE EPOCH AHEAD, so that an epoch switch inside a training loop is a pointer swap.  (Until round 3 the
+        permutation was drawn on the host and copied synchronously at every epoch start: bench.py's 20-step timed regions of the
+        driver's form cannot hide a host stall and read 4 % above the 200-step regions; an asynchronous pinned-memory upload
+        behind a deep launch queue was worse: intermittent 25-80 ms stalls.)"""
         U = self.indptr.numel() - 1
-        perm = np.random.RandomState((self.seed + epoch) % (2 ** 32)).permutation(U).astype(np.int32)
-        self.perm = torch.as_tensor(perm, device=self.device)
-        lens = (self.indptr[1:] - self.indptr[:-1]).index_select(0, self.perm.long())
-        self.epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
-        torch.cumsum(lens, 0, out=self.epoch_ptr[1:])
+        if getattr(self, "_iota", None) is None:
+            self._iota = torch.arange(U, dtype=torch.int32, device=self.device)
+        keys = torch.empty(U, dtype=torch.int64, device=self.device)
+        rc = self.lib.bprx_epoch_keys(self.seed, epoch, U, _ptr(keys), _stream())
+        if rc < 0:
+            raise _ffi.BprxError(rc, "bprx_epoch_keys failed")
+        perm_d = torch.sort(keys, stable=True).indices.to(torch.int32)
+        lens = (self.indptr[1:] - self.indptr[:-1]).index_select(0, perm_d.long())
+        epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens, 0, out=epoch_ptr[1:])
         # position -> slot of its user in the epoch order, once per epoch (4 B per interaction): saves the per-triplet
         # binary search over epoch_ptr in the kernel
-        self.pos_slot = torch.repeat_interleave(torch.arange(U, dtype=torch.int32, device=self.device), lens)
+        pos_slot = torch.repeat_interleave(self._iota, lens, output_size=self.num_pos)
+        return dict(epoch=epoch, perm=perm_d, epoch_ptr=epoch_ptr, pos_slot=pos_slot)
+
+    def _start_epoch(self, epoch):
+        nxt = getattr(self, "_next", None)
+        cur = nxt if (nxt is not None and nxt["epoch"] == epoch) else self._prepare(epoch)
+        self.perm, self.epoch_ptr, self.pos_slot = cur["perm"], cur["epoch_ptr"], cur["pos_slot"]
         self.epoch, self.pos_in_epoch = epoch, 0
+        self._next = self._prepare(epoch + 1)
 
     def sample(self, B, first=None, out=None):
         if first is not None:

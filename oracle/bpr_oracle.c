@@ -564,6 +564,15 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* sort keys of an epoch's user order (twin of k_epoch_keys): 63 bits of philox(key = seed, ctr = (u, 0, 0xFFFFFFFF, epoch)) */
+void orc_epoch_keys(uint64_t seed, uint32_t epoch, int32_t U, int64_t *keys) {
+  for (int32_t u = 0; u < U; u++) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)u, 0, 0xFFFFFFFFu, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    keys[u] = (int64_t)((((uint64_t)(r[1] & 0x7fffffffu)) << 32) | r[0]);
+  }
+}
+
 void orc_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user, int64_t N,
                        int32_t I, uint64_t seed, uint64_t first, int64_t B, int32_t *u, int32_t *i, int32_t *j) {
   for (int64_t b = 0; b < B; b++) {

@@ -59,6 +59,7 @@ def lib():
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_sample_epoch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64,
                                        C.c_uint32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_epoch_keys.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]
         L.orc_e4m3_round_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_bf16_round.restype = C.c_float
         L.orc_bf16_round.argtypes = [C.c_float]
@@ -110,11 +111,18 @@ def sample_philox(train_lists, num_items, seed, first, B):
     return u, i, j
 
 
+def epoch_perm(seed, epoch, U):
+    keys = np.empty(U, np.int64)
+    lib().orc_epoch_keys(seed, epoch, U, _p(keys))
+    return np.argsort(keys, kind="stable").astype(np.int32)
+
+
 def sample_epoch(train_lists, num_items, seed, epoch, first, B):
-    """Twin of EpochWalkSampler for one epoch: same host permutation RandomState(seed + epoch), same prefix sums."""
+    """Twin of EpochWalkSampler for one epoch: the user order is the stable argsort of the Philox keys (bprx_epoch_keys), same
+    prefix sums."""
     indptr, items, _ = interactions_csr(train_lists)
     U = len(train_lists)
-    perm = np.random.RandomState((seed + epoch) % (2 ** 32)).permutation(U).astype(np.int32)
+    perm = epoch_perm(seed, epoch, U)
     eptr = np.zeros(U + 1, np.int64)
     eptr[1:] = np.cumsum(np.diff(indptr)[perm])
     u = np.empty(B, np.int32); i = np.empty(B, np.int32); j = np.empty(B, np.int32)

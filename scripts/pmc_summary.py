@@ -40,11 +40,12 @@ def mfma_busy(m):
 
 
 if json_out:
-    phases = {"proj_fwd": "k_proj_fwd_bf16_v", "proj_bwd": "k_proj_bwd_bf16_v3", "triplet_grad": "k_triplet_grad",
-              "item_seg": "k_item_seg", "dense_update": "k_dense_update", "row_count": "k_row_count", "apply": "k_apply_sgd"}
+    phases = {"proj_fwd": ("k_proj_fwd_bf16_v10", "k_proj_fwd_f8s"), "proj_bwd": ("k_proj_bwd_bf16_v3",),
+              "triplet_grad": ("k_triplet_seg", "k_triplet_grad"), "item_seg": ("k_item_seg",), "dense_update": ("k_dense_update",),
+              "row_count": ("k_index_seg", "k_row_count"), "apply": ("k_apply_sgd",), "sampler": ("k_sample_epoch", "k_sample_philox")}
     out = {}
     for ph, pat in phases.items():
-        ks = [k for k in mean if k.startswith(pat)]
+        ks = [k for k in mean if any(k.startswith(p_) for p_ in pat)]
         if not ks:
             continue
         k = max(ks, key=lambda q: len(acc[q].get("FETCH_SIZE", [])) + len(acc[q].get("SQ_WAVES", [])))
