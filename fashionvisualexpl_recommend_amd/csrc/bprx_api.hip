@@ -28,7 +28,8 @@ static void graph_drop(bprx_handle *h) {
 }
 
 static bprx_handle::GraphSig graph_sig(const bprx_handle *h) {
-  return {h->list_slot, h->slist_slot, h->qs_slot, h->seg_slot, h->et_valid, h->p_valid, h->absmax_valid, h->W_dirty};
+  return {h->list_slot, h->slist_slot, h->qs_slot, h->seg_slot, h->et_valid, h->p_valid, h->absmax_valid, h->W_dirty,
+          h->idx8_ready((const int32_t *)h->graph_key.i, (const int32_t *)h->graph_key.j, h->graph_key.B)};
 }
 static void graph_sig_apply(bprx_handle *h, const bprx_handle::GraphSig &g) {
   h->list_slot = g.list_slot; h->slist_slot = g.slist_slot; h->qs_slot = g.qs_slot; h->seg_slot = g.seg_slot;
@@ -36,13 +37,14 @@ static void graph_sig_apply(bprx_handle *h, const bprx_handle::GraphSig &g) {
 }
 static bool graph_sig_eq(const bprx_handle::GraphSig &a, const bprx_handle::GraphSig &b) {
   return a.list_slot == b.list_slot && a.slist_slot == b.slist_slot && a.qs_slot == b.qs_slot && a.seg_slot == b.seg_slot &&
+         a.idx8 == b.idx8 &&
          a.et_valid == b.et_valid &&
          a.p_valid == b.p_valid && a.absmax_valid == b.absmax_valid && a.W_dirty == b.W_dirty;
 }
 
 static void free_scratch(bprx_handle *h) {
   void *ptrs[] = {h->dGu, h->dGi, h->dBi, h->dTu, h->flagU, h->flagI, h->lossb, h->loss_acc, h->errflag,
-                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_cnt, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->uslot_of, h->ulist, h->uold, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
+                  h->P,   h->W,   h->Wb, h->Ppair, h->Et, h->EtF, h->EtS, h->dEp, h->part, h->qs, h->Ft, h->seg_rank, h->seg_cnt, h->seg_ptr, h->seg_cursor, h->seg_lead, h->seg_ent, h->hot_done, h->uslot_of, h->ulist, h->uold, h->own8, h->loc8, h->cntU, h->cntI, h->ilist, h->ilist_n, h->lastU, h->lastI, h->lr_hist, h->slist, h->slist_n, h->msg_cursor, h->msg_next};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -169,7 +171,9 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
                  dalloc_zero((int4 **)&h->seg_lead, (size_t)h->seg_lead_cap) == hipSuccess &&
                  dalloc_zero(&h->hot_done, I) == hipSuccess && dalloc_zero((int2 **)&h->seg_ent, (size_t)h->seg_ent_cap) == hipSuccess &&
                  dalloc_zero(&h->uslot_of, U) == hipSuccess && dalloc_zero(&h->ulist, MB) == hipSuccess &&
-                 dalloc_zero(&h->uold, MB * (k + d)) == hipSuccess;
+                 dalloc_zero(&h->uold, MB * (k + d)) == hipSuccess &&
+                 (I > 65536 || (getenv("BPRX_IDX8") && atoi(getenv("BPRX_IDX8")) == 0) ||     // BPRX_IDX8=0: no byte planes (A/B)
+                  (dalloc_zero(&h->own8, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->loc8, (size_t)2 * MB) == hipSuccess));
       if (!ok2) {
         snprintf(g_create_err, sizeof(g_create_err), "segment scratch allocation failed");
         free_scratch(h);
@@ -421,6 +425,9 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
   h->list_mode = vb && !h->proj_fresh && (h->list_policy == 2 || (h->list_policy == 1 && 2 * B < (int64_t)h->cfg.num_items));
   h->item_mode = !h->list_mode && (h->seg_policy == 2 || (h->seg_policy == 1 && 2 * B >= (int64_t)h->cfg.num_items));
   h->list_reset_cnt = !(h->fast_rows && !(h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD));
+  // byte planes of this very batch, left by bprx_sample_*_h (consumed here, whatever this step does with them)
+  h->idx8_use = h->idx8_ready(pos, neg, B);
+  h->idx8_n = 0;
   float lr_t = h->cfg.lr;
   bool catchup_aside = false;     // BPRX_SIDE_STREAM & 4: the (ALU-bound) lazy-Adam catch-up runs beside the (HBM-bound) projection
   if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
@@ -614,6 +621,7 @@ extern "C" int bprx_step(bprx_handle *h, const int32_t *user, const int32_t *pos
   for (int q = 0; q < h->graph_n; ++q)
     if (graph_sig_eq(h->graph_ents[q].in, in)) {
       BPRX_HIP(h, hipGraphLaunch(h->graph_ents[q].exec, s));
+      h->idx8_n = 0;                                         // (byte planes of this batch, if any: consumed)
       graph_sig_apply(h, h->graph_ents[q].out);              // what the launches of the captured step left on the host
       return BPRX_OK;
     }
@@ -657,6 +665,8 @@ extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *o
     return bprx_launch_score_gemm(h, u0, u1, out, s);          // fp32 MFMA GEMM (K step 2)
   return bprx_launch_score_block(h, u0, u1, out, s);
 }
+
+extern "C" int bprx_index_pass_kind(const bprx_handle *h) { return h ? h->idx_kind : 0; }
 
 extern "C" int bprx_sync_check(bprx_handle *h, void *stream) {
   if (!h) return BPRX_E_INVALID;

@@ -76,6 +76,18 @@ struct bprx_handle {
   int32_t *uslot_of;              // [U] batch position of the user's first run head = the user's slot (valid for users of the batch)
   int32_t *ulist;                 // [max_batch] the batch's users (first-run order): walked by k_item_seg's finishing groups
   float *uold;                    // [max_batch][k + d] pre-update [gamma_u | theta_u] of the slot's user
+  // byte planes of the item ids of the NEXT step's batch, written by the library's own device samplers (bprx_sample_*_h) when
+  // num_items <= 65 536: own8 = id >> 8 (the owner workgroup of k_index_seg, 256 items each), loc8 = id & 255; [2 * max_batch]
+  // each (positives, then negatives).  idx8_pos / idx8_neg / idx8_B: the buffers and batch size they belong to; idx8_n: triplets
+  // filled so far (-1: invalid); consumed (idx8_n = 0) by the step that uses them.
+  uint8_t *own8, *loc8;
+  const int32_t *idx8_pos, *idx8_neg;
+  int64_t idx8_B, idx8_n;
+  bool idx8_use;                  // this step's index pass scans the byte planes
+  int idx_kind;                   // bprx_index_pass_kind
+  bool idx8_ready(const int32_t *pos, const int32_t *neg, int64_t B) const {
+    return item_mode && own8 && B > 0 && idx8_n == B && idx8_B == B && idx8_pos == pos && idx8_neg == neg && B % 16 == 0;
+  }
   int32_t *hot_done;              // [I] finished chunks of a hot item (k_item_seg), all-zero between steps
   void *seg_ent;                  // [seg_ent_cap] 8-byte entries {user or user slot | role << 31, g_b}: the owners' regions (twice
                                   //     the expected occupancy each) + 2 * max_batch for the owners that overflow theirs
@@ -115,7 +127,7 @@ struct bprx_handle {
   // step to step, validity of the derived images), so an exec is stored with the state it was captured in and the state
   // it leaves, and is replayed only from the same state; a steady training loop alternates between two execs.
   int graph_mode;                 // env BPRX_GRAPH: 0 (default) = never, 1 = always, 2 = small steps only (B <= 8192)
-  struct GraphSig { int list_slot, slist_slot, qs_slot, seg_slot; bool et_valid, p_valid, absmax_valid, W_dirty; };
+  struct GraphSig { int list_slot, slist_slot, qs_slot, seg_slot; bool et_valid, p_valid, absmax_valid, W_dirty, idx8; };
   struct GraphEnt { hipGraphExec_t exec; GraphSig in, out; };
   GraphEnt graph_ents[4];
   int graph_n;

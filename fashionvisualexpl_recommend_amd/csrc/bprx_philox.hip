@@ -9,7 +9,7 @@
 // is bit-exact.  One thread per triplet; 12 B written per triplet.
 #include <hip/hip_runtime.h>
 
-#include "bprx.h"
+#include "bprx_internal.h"
 
 namespace {
 
@@ -29,7 +29,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict__ indptr, const int32_t *__restrict__ items,
                                                        const int32_t *__restrict__ pos_user, unsigned long long N, uint32_t I,
                                                        uint32_t k0, uint32_t k1, unsigned long long first, long long B,
-                                                       int32_t *__restrict__ u, int32_t *__restrict__ i, int32_t *__restrict__ j) {
+                                                       int32_t *__restrict__ u, int32_t *__restrict__ i, int32_t *__restrict__ j,
+                                                       uint8_t *__restrict__ own8, uint8_t *__restrict__ loc8, long long pl_i,
+                                                       long long pl_j) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const unsigned long long n = first + (unsigned long long)b;
@@ -51,7 +53,12 @@ __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict
     }
     if (!(lo < len && lst[lo] == jj)) break;
   }
-  u[b] = uu; i[b] = items[p]; j[b] = jj;
+  const int32_t ii = items[p];
+  u[b] = uu; i[b] = ii; j[b] = jj;
+  if (own8) {                                           // byte planes of the item ids for the handle's index pass (k_index_seg)
+    own8[pl_i + b] = (uint8_t)(ii >> 8); loc8[pl_i + b] = (uint8_t)ii;
+    own8[pl_j + b] = (uint8_t)(jj >> 8); loc8[pl_j + b] = (uint8_t)jj;
+  }
 }
 
 // Epoch-walk mode (the reference's order, dataset.py:93-107, as a stateless stream): within epoch e the users come in the
@@ -63,7 +70,9 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
                                                       const int32_t *__restrict__ perm, const int64_t *__restrict__ epoch_ptr,
                                                       const int32_t *__restrict__ pos_slot, int U, uint32_t I, uint32_t k0, uint32_t k1, uint32_t epoch,
                                                       long long first, long long B, int32_t *__restrict__ u,
-                                                      int32_t *__restrict__ i, int32_t *__restrict__ j) {
+                                                      int32_t *__restrict__ i, int32_t *__restrict__ j,
+                                                      uint8_t *__restrict__ own8, uint8_t *__restrict__ loc8, long long pl_i,
+                                                      long long pl_j) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const long long n = first + b;
@@ -89,7 +98,12 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
     }
     if (!(l < len && lst[l] == jj)) break;
   }
-  u[b] = uu; i[b] = lst[n - epoch_ptr[lo]]; j[b] = jj;
+  const int32_t ii = lst[n - epoch_ptr[lo]];
+  u[b] = uu; i[b] = ii; j[b] = jj;
+  if (own8) {
+    own8[pl_i + b] = (uint8_t)(ii >> 8); loc8[pl_i + b] = (uint8_t)ii;
+    own8[pl_j + b] = (uint8_t)(jj >> 8); loc8[pl_j + b] = (uint8_t)jj;
+  }
 }
 
 // Sort keys of an epoch's user order: key[u] = 63 bits of philox(key = seed, ctr = (u, 0, 0xFFFFFFFF, epoch)) -- the third
@@ -112,28 +126,67 @@ extern "C" int bprx_epoch_keys(uint64_t seed, uint32_t epoch, int32_t num_users,
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 
-extern "C" int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
-                                 const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items, uint64_t seed,
-                                 uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
-                                 void *stream) {
+// `h` (optional): the handle whose next step will run on these buffers.  When its index pass can use them (segment mode,
+// num_items <= 65 536, whole batch a multiple of 16), the sampler also writes the high and the low byte of every item id into
+// the handle's byte planes (2 B per occurrence): k_index_seg's owners then scan ONE byte per occurrence -- sixteen values per
+// 16-byte load, tested together -- instead of four bytes and a compare per value.  batch_offset / batch_size: this call fills
+// triplets [batch_offset, batch_offset + B) of a batch of batch_size (an epoch crossing fills a batch in two calls); the planes
+// are valid for the step that is called with exactly these buffers and B = batch_size, and are consumed by it.
+static void plane_args(bprx_handle *h, const int32_t *pos, const int32_t *neg, int64_t B, int64_t batch_offset, int64_t batch_size,
+                       uint8_t **own8, uint8_t **loc8, long long *pl_i, long long *pl_j) {
+  *own8 = nullptr; *loc8 = nullptr; *pl_i = 0; *pl_j = 0;
+  if (!h || !h->own8 || batch_size <= 0 || batch_size > h->cfg.max_batch || batch_offset < 0 || batch_offset + B > batch_size) return;
+  const int32_t *pos0 = pos - batch_offset, *neg0 = neg - batch_offset;
+  if (batch_offset == 0) { h->idx8_pos = pos0; h->idx8_neg = neg0; h->idx8_B = batch_size; h->idx8_n = 0; }
+  else if (h->idx8_pos != pos0 || h->idx8_neg != neg0 || h->idx8_B != batch_size) { h->idx8_n = -1; return; }
+  if (h->idx8_n < 0) return;
+  h->idx8_n += B;
+  *own8 = h->own8; *loc8 = h->loc8; *pl_i = batch_offset; *pl_j = batch_size + batch_offset;
+}
+
+extern "C" int bprx_sample_epoch_h(bprx_handle *h, const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
+                                   const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items,
+                                   uint64_t seed, uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
+                                   int64_t batch_offset, int64_t batch_size, void *stream) {
   if (!indptr || !items_sorted || !perm || !epoch_ptr || !user || !pos || !neg || num_users <= 0 || num_items <= 0 ||
       B < 0 || first < 0)
     return BPRX_E_INVALID;
   if (B == 0) return BPRX_OK;
+  uint8_t *own8, *loc8;
+  long long pl_i, pl_j;
+  plane_args(h, pos, neg, B, batch_offset, batch_size, &own8, &loc8, &pl_i, &pl_j);
   hipLaunchKernelGGL(k_sample_epoch, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
                      items_sorted, perm, epoch_ptr, pos_slot, num_users, (uint32_t)num_items, (uint32_t)seed, (uint32_t)(seed >> 32),
-                     epoch, (long long)first, (long long)B, user, pos, neg);
+                     epoch, (long long)first, (long long)B, user, pos, neg, own8, loc8, pl_i, pl_j);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}
+
+extern "C" int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
+                                 const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items, uint64_t seed,
+                                 uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
+                                 void *stream) {
+  return bprx_sample_epoch_h(nullptr, indptr, items_sorted, perm, epoch_ptr, pos_slot, num_users, num_items, seed, epoch, first, B,
+                             user, pos, neg, 0, 0, stream);
+}
+
+extern "C" int bprx_sample_philox_h(bprx_handle *h, const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user,
+                                    int64_t num_pos, int32_t num_items, uint64_t seed, uint64_t first, int64_t B, int32_t *user,
+                                    int32_t *pos, int32_t *neg, int64_t batch_offset, int64_t batch_size, void *stream) {
+  if (!indptr || !items_sorted || !pos_user || !user || !pos || !neg || num_pos <= 0 || num_items <= 0 || B < 0)
+    return BPRX_E_INVALID;
+  if (B == 0) return BPRX_OK;
+  uint8_t *own8, *loc8;
+  long long pl_i, pl_j;
+  plane_args(h, pos, neg, B, batch_offset, batch_size, &own8, &loc8, &pl_i, &pl_j);
+  hipLaunchKernelGGL(k_sample_philox, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
+                     items_sorted, pos_user, (unsigned long long)num_pos, (uint32_t)num_items, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (unsigned long long)first, (long long)B, user, pos, neg, own8, loc8, pl_i, pl_j);
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 
 extern "C" int bprx_sample_philox(const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user,
                                   int64_t num_pos, int32_t num_items, uint64_t seed, uint64_t first, int64_t B,
                                   int32_t *user, int32_t *pos, int32_t *neg, void *stream) {
-  if (!indptr || !items_sorted || !pos_user || !user || !pos || !neg || num_pos <= 0 || num_items <= 0 || B < 0)
-    return BPRX_E_INVALID;
-  if (B == 0) return BPRX_OK;
-  hipLaunchKernelGGL(k_sample_philox, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
-                     items_sorted, pos_user, (unsigned long long)num_pos, (uint32_t)num_items, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), (unsigned long long)first, (long long)B, user, pos, neg);
-  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+  return bprx_sample_philox_h(nullptr, indptr, items_sorted, pos_user, num_pos, num_items, seed, first, B, user, pos, neg, 0, 0,
+                              stream);
 }

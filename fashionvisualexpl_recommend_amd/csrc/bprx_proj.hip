@@ -435,7 +435,11 @@ __device__ __forceinline__ void fp8x4_to_bf16x4(uint32_t w, uint32_t &o0, uint32
 // DB = 2: two LDS images used by alternate tiles -- the barrier that protects an image from being overwritten while other
 // waves still read it disappears (one barrier per tile instead of two) and a wave's commit of tile t+1 (for fp8 tables:
 // the widening to bf16) overlaps the other waves' MFMAs of tile t.  For the MFMA-paced shapes (fp8 tables, wide projections).
-template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS = false, int DB = 1>
+// NS (wave grid): the NW waves form (NW / NS) x NS; a wave owns 2*NS of the workgroup's feature-column tiles and ceil(NT / NS)
+// of the projection's column tiles.  Per 32 items a wave reads (2*NS + NT/NS) KB of fragments from LDS for 2*NT MFMAs; NS = 1
+// at NT = 17 is 19 KB for 34 -- the transpose reads, 64 B/clk per CU, take 2.2x the MFMAs' time and pace the kernel (c5: 1 024 us
+// measured, 990 us by that count); NS = 2 is 13 KB for 36.
+template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS = false, int DB = 1, int NS = 1>
 __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__restrict__ F, int nrows, int D,
                                                           const uint16_t *__restrict__ Wb, int PS, float *__restrict__ part,
                                                           int rows_per_split, int descend, int xcd_map,
@@ -477,11 +481,14 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
   int tend = tbeg + rows_per_split;
   if (tend > nrows) tend = nrows;
   const int ntiles = tend > tbeg ? (tend - tbeg + BTV - 1) / BTV : 0;
-  f32x4 acc[2][NT];
+  static_assert(NW % NS == 0, "wave grid");
+  constexpr int MTW = 2 * NS, NTW = (NT + NS - 1) / NS;
+  const int wm = w / NS, wn = w % NS;
+  f32x4 acc[MTW][NTW];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // PD tiles are in flight per workgroup (registers: PD * (FPT + WPT) * 4 VGPRs): the loop is latency-bound on the
   // global loads, so bytes in flight per CU set the delivered bandwidth
   uint4 freg[PD][FPT], wreg[PD][WPT];
@@ -578,22 +585,23 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
     for (int kk = 0; kk < BTV / 32; ++kk) {
       const int rlo = kk * 32 + 8 * g + qq, rhi = rlo + 4;       // (rlo & 8) == (rhi & 8) == 8*(g & 1)
       const int disp = (g & 1) << 7;
-      bf16x8 a[2];
+      bf16x8 a[MTW];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int cb = (((w * 2 + mt) * 16 + 4 * p) * 2) ^ disp;
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int cb = (((wm * MTW + mt) * 16 + 4 * p) * 2) ^ disp;
         bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rlo * FSB + cb]));
         bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Fs[rhi * FSB + cb]));
         a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int cb = (nt * 16 + 4 * p) * 2 + disp;
+      for (int nt = 0; nt < NTW; ++nt) {
+        if (NS > 1 && wn * NTW + nt >= NT) break;                   // (wave-uniform: the last wave column has fewer tiles)
+        const int cb = ((wn * NTW + nt) * 16 + 4 * p) * 2 + disp;
         bf16x4 lo = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rlo * WSB + cb]));
         bf16x4 hi = lds_tr16(reinterpret_cast<const uint16_t *>(&Ws[rhi * WSB + cb]));
         const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
       }
     }
    }
@@ -602,12 +610,13 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
 #undef BWD3_COMMIT
   float *slab = part + ((size_t)by * D + m0) * PS;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int m = (w * 2 + mt) * 16 + g * 4 + reg;
+      const int m = (wm * MTW + mt) * 16 + g * 4 + reg;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) slab[(size_t)m * PS + nt * 16 + i16] = acc[mt][nt][reg];
+      for (int nt = 0; nt < NTW; ++nt)
+        if (NS == 1 || wn * NTW + nt < NT) slab[(size_t)m * PS + (wn * NTW + nt) * 16 + i16] = acc[mt][nt][reg];
     }
 }
 
@@ -1257,11 +1266,11 @@ int launch_fwd_nt(bprx_handle *h, const int32_t *rows, int64_t nrows, float *Pou
 }
 
 // one launch of k_proj_bwd_bf16_v3 with its dynamic LDS size (DB images of F tile + W tile)
-template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS, int DB>
+template <int NT, int BTV, int NW, int PD, bool F8, bool ROWS, int DB, int NS = 1>
 void launch_bwd3(dim3 grid, hipStream_t s, const uint16_t *Ft, int nrows, int D, const uint16_t *Wb, int PS, float *part, int rps,
                  int desc, int xmap, const int32_t *rows, const int32_t *nrows_dev, const float *Wf) {
   constexpr size_t lds = (size_t)DB * (BTV * (NW * 32 * 2 + 32) + BTV * WsStride3<NT>::bytes);
-  auto kfn = k_proj_bwd_bf16_v3<NT, BTV, NW, PD, F8, ROWS, DB>;
+  auto kfn = k_proj_bwd_bf16_v3<NT, BTV, NW, PD, F8, ROWS, DB, NS>;
   if (lds > 48 * 1024) {
     static bool attr_set = false;                        // per instantiation
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -1306,6 +1315,12 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   dim3 g3(D / (w8 ? 256 : 128), h->SK);
 #define BWD3_ARGS (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, 0, 1, (const int32_t *)nullptr, \
                   (const int32_t *)nullptr, (const float *)nullptr
+  static const int ns_env = getenv("BPRX_BWD_NS") ? atoi(getenv("BPRX_BWD_NS")) : 0;       // A/B: 1 = one wave column, 2 = two
+  const int ns = ns_env ? ns_env : (NT > 9 ? 2 : 1);
+  if constexpr (NT > 5) {
+    if (f8 && ns == 2) { launch_bwd3<NT, 32, 8, 2, true, false, 2, 2>(g3, s, BWD3_ARGS); return 0; }
+    if (!f8 && w8 && NT > 9 && ns == 2) { launch_bwd3<NT, 32, 8, 2, false, false, 2, 2>(g3, s, BWD3_ARGS); return 0; }
+  }
   if (f8) launch_bwd3<NT, 32, 8, 2, true, false, 2>(g3, s, BWD3_ARGS);
   else if (w8 && NT > 9) launch_bwd3<NT, 32, 8, 2, false, false, 2>(g3, s, BWD3_ARGS);
   else if (w8) launch_bwd3<NT, 32, 8, 3, false, false, 1>(g3, s, BWD3_ARGS);

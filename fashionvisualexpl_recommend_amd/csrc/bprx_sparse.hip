@@ -1059,6 +1059,9 @@ struct IndexSegArgs {
   uint16_t *Wb;                   // bf16 W image (rows of untouched items are zeroed) or nullptr
   int PS;
   int aligned;                    // pos / neg are 16-byte aligned
+  // byte planes of the batch's item ids (positives, then negatives; written by bprx_sample_*_h) or nullptr.  With them
+  // R == 256 and B % 16 == 0: owner w scans own8 for bytes equal to w, sixteen values per 16-byte load.
+  const uint8_t *own8, *loc8;
 };
 
 __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
@@ -1123,6 +1126,50 @@ __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
     const unsigned mn = min(min(x0, x1), min(x2, x3));
     if (in && mn <= Wm) { one(v.x, occ); one(v.y, occ + 1); one(v.z, occ + 2); one(v.w, occ + 3); }
   };
+  if (a.own8) {
+    // one byte per occurrence: y = plane ^ (w in every byte) has a zero byte where the occurrence is mine; the classic
+    // (y - 0x01..) & ~y & 0x80.. test is exact for "any zero byte in the dword", and the four dwords of a load are OR-ed before
+    // the one compare.  A lane with a match (16 values in `nown`) finds the bytes with the exact per-byte mask and ranks them;
+    // their low bytes (item - lo) come from the second plane, loaded beside the first (a dependent load would be waited for).
+    const uint4 *o4 = reinterpret_cast<const uint4 *>(a.own8), *l4 = reinterpret_cast<const uint4 *>(a.loc8);
+    const int n16 = (int)((2 * a.B) >> 4);
+    const int nblk = (n16 + IX_T - 1) / IX_T;
+    const int rot = nblk ? (int)((((unsigned)w * 2654435761u) >> 8) % (unsigned)nblk) : 0;
+    const unsigned wp = (unsigned)w * 0x01010101u;
+    auto dword = [&](unsigned o, unsigned l, int occ) {
+      const unsigned y = o ^ wp;
+      unsigned m = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);        // 0x80 in every zero byte of y, nowhere else
+      while (m) {
+        const int by = (__ffs((int)m) - 1) >> 3;
+        a.seg_rank[occ + by] = atomicAdd(&cnt[(l >> (8 * by)) & 255u], 1);
+        m &= m - 1;
+      }
+    };
+    for (int blk = 0; blk < nblk; blk += 8) {
+      uint4 vo[8], vl[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        int bb = blk + x + rot;
+        bb = bb >= nblk ? bb - nblk : bb;
+        const int e = bb * IX_T + tid;
+        vo[x] = o4[e < n16 ? e : n16 - 1];
+        vl[x] = l4[e < n16 ? e : n16 - 1];
+      }
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        int bb = blk + x + rot;
+        bb = bb >= nblk ? bb - nblk : bb;
+        const int e = bb * IX_T + tid;
+        const unsigned y0 = vo[x].x ^ wp, y1 = vo[x].y ^ wp, y2 = vo[x].z ^ wp, y3 = vo[x].w ^ wp;
+        const unsigned any = (((y0 - 0x01010101u) & ~y0) | ((y1 - 0x01010101u) & ~y1) | ((y2 - 0x01010101u) & ~y2) |
+                              ((y3 - 0x01010101u) & ~y3)) & 0x80808080u;
+        if (blk + x < nblk && e < n16 && any) {
+          dword(vo[x].x, vl[x].x, 16 * e); dword(vo[x].y, vl[x].y, 16 * e + 4);
+          dword(vo[x].z, vl[x].z, 16 * e + 8); dword(vo[x].w, vl[x].w, 16 * e + 12);
+        }
+      }
+    }
+  } else
 #pragma unroll 1
   for (int role = 0; role < 2; ++role) {
     const int32_t *arr = role ? a.neg : a.pos;
@@ -1997,6 +2044,9 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
     if ((a.I + nown - 1) / nown > IX_RMAX) nown = (a.I + IX_RMAX - 1) / IX_RMAX;   // ... more when a range would not fit LDS
     if (nown > a.I) nown = a.I;
     x.R = (a.I + nown - 1) / nown;
+    x.own8 = x.loc8 = nullptr;
+    h->idx_kind = 1;
+    if (h->idx8_use && a.I <= 65536) { x.R = 256; x.own8 = h->own8; x.loc8 = h->loc8; h->idx_kind = 2; }    // the sampler left byte planes of this batch
     x.nown = (a.I + x.R - 1) / x.R;
     x.seg_rank = h->seg_rank; x.seg_cnt = h->seg_cnt; x.seg_ptr = h->seg_ptr;
     x.Ce = (int)(2 * ((2 * B + x.nown - 1) / x.nown) + 64);

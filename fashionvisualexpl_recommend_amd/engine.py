@@ -346,13 +346,20 @@ class PhiloxSampler:
         self.num_pos, self.num_items, self.seed, self.next = int(items_sorted.numel()), int(num_items), int(seed), 0
         return self
 
+    def feeds(self, engine):
+        """Name the engine whose steps consume this sampler's batches (bprx_sample_*_h): the sampler then also leaves the byte
+        planes of the item ids that engine's index pass scans (segment mode, <= 65 536 items).  Returns self."""
+        self._handle = engine.h if engine is not None else None
+        return self
+
     def sample(self, B, first=None, out=None):
         """B triplets starting at stream position `first` (default: continue).  Returns int32 device tensors."""
         if first is None:
             first, self.next = self.next, self.next + B
         u, i, j = out if out is not None else tuple(torch.empty(B, dtype=torch.int32, device=self.device) for _ in range(3))
-        rc = self.lib.bprx_sample_philox(_ptr(self.indptr), _ptr(self.items), _ptr(self.pos_user), self.num_pos,
-                                         self.num_items, self.seed, first, B, _ptr(u), _ptr(i), _ptr(j), _stream())
+        rc = self.lib.bprx_sample_philox_h(getattr(self, "_handle", None), _ptr(self.indptr), _ptr(self.items), _ptr(self.pos_user),
+                                           self.num_pos, self.num_items, self.seed, first, B, _ptr(u), _ptr(i), _ptr(j), 0, B,
+                                           _stream())
         if rc < 0:
             raise _ffi.BprxError(rc, "bprx_sample_philox failed")
         return u, i, j
@@ -403,9 +410,10 @@ class EpochWalkSampler(PhiloxSampler):
         done = 0
         while done < B:
             n = min(B - done, self.num_pos - self.pos_in_epoch)
-            rc = self.lib.bprx_sample_epoch(_ptr(self.indptr), _ptr(self.items), _ptr(self.perm), _ptr(self.epoch_ptr),
-                                            _ptr(self.pos_slot), self.indptr.numel() - 1, self.num_items, self.seed, self.epoch,
-                                            self.pos_in_epoch, n, _ptr(u[done:]), _ptr(i[done:]), _ptr(j[done:]), _stream())
+            rc = self.lib.bprx_sample_epoch_h(getattr(self, "_handle", None), _ptr(self.indptr), _ptr(self.items), _ptr(self.perm),
+                                              _ptr(self.epoch_ptr), _ptr(self.pos_slot), self.indptr.numel() - 1, self.num_items,
+                                              self.seed, self.epoch, self.pos_in_epoch, n, _ptr(u[done:]), _ptr(i[done:]),
+                                              _ptr(j[done:]), done, B, _stream())
             if rc < 0:
                 raise _ffi.BprxError(rc, "bprx_sample_epoch failed")
             done += n

@@ -154,7 +154,7 @@ class BPRMF(RecommenderModel):
             # CPU twin in the oracle) instead of the host MT19937 stream -- no index upload per step
             from .engine import EpochWalkSampler
             smp = EpochWalkSampler(self.data.training_list, self.num_items, device=self.engine.device,
-                                   seed=getattr(self.params, "init_seed", 0))
+                                   seed=getattr(self.params, "init_seed", 0)).feeds(self.engine)
             next_batch = (smp.sample(self.params.batch_size) for _ in range(steps_total))
         else:
             next_batch = self.data.next_triple_batch(self.engine.device)

@@ -338,6 +338,25 @@ BPRX_API int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorte
                                uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
                                void *stream);
 
+/* The same two samplers, told which handle's NEXT step will consume the batch (h may be NULL: exactly the calls above).
+   When that handle steps in segment mode with num_items <= 65 536, the sampler also writes the high and the low byte of every
+   sampled item id into byte planes the handle owns (2 B per occurrence); the index pass of the step called with exactly these
+   pos / neg pointers and B == batch_size (a multiple of 16) then scans one byte per occurrence instead of four (its owner
+   workgroups each read the whole batch).  batch_offset / batch_size: this call fills triplets [batch_offset, batch_offset + B)
+   of a batch of batch_size, whose arrays start at user - batch_offset, pos - batch_offset, neg - batch_offset (an epoch
+   crossing fills a batch in two calls; the call with batch_offset 0 comes first).  The caller must not change pos / neg between
+   the sampler and the step; any other step on the handle simply ignores (and drops) the planes.  Results are identical. */
+BPRX_API int bprx_sample_philox_h(bprx_handle *h, const int64_t *indptr, const int32_t *items_sorted, const int32_t *pos_user,
+                                  int64_t num_pos, int32_t num_items, uint64_t seed, uint64_t first, int64_t B, int32_t *user,
+                                  int32_t *pos, int32_t *neg, int64_t batch_offset, int64_t batch_size, void *stream);
+BPRX_API int bprx_sample_epoch_h(bprx_handle *h, const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
+                                 const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items,
+                                 uint64_t seed, uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
+                                 int64_t batch_offset, int64_t batch_size, void *stream);
+/* What the index pass of the handle's last step read: 0 = no segment-mode step yet, 1 = the int32 index arrays,
+   2 = the sampler's byte planes.  (Introspection for tests and benchmarks.) */
+BPRX_API int bprx_index_pass_kind(const bprx_handle *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,39 @@ def test_segment_step_reports_out_of_range_indices_without_faulting(monkeypatch)
     e.step(*(torch.as_tensor(a, device="cuda") for a in (u, i, j)))
     e.sync_check()
     assert all(np.isfinite(e.t[n].cpu().numpy()).all() for n in ("Gu", "Gi", "Bi"))
+
+
+@pytest.mark.parametrize("kind", ["epoch", "philox"])
+def test_index_pass_on_the_samplers_byte_planes(kind, monkeypatch):
+    """bprx_sample_*_h leave the byte planes of the item ids; the step on exactly that batch scans them (kind 2) and must give
+    what the oracle gives on the same triplets -- including a batch filled by two sampler calls (epoch crossing), a partial
+    last owner (I % 256 != 0), and the fall-backs to the int32 scan: other buffers, B % 16 != 0, planes of another batch."""
+    monkeypatch.setenv("BPRX_ITEM_MODE", "2")
+    from fashionvisualexpl_recommend_amd.engine import Engine, EpochWalkSampler, PhiloxSampler
+    U, I, k, B = 300, 1000, 32, 512
+    t = _tables(U, I, k, 0, 0, seed=9)
+    lr, reg = 0.05, 1e-3
+    e = Engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=lr, reg=reg, max_batch=B).bind(**t)
+    o = orc.OracleModel(**t, quant=0)
+    rs = np.random.RandomState(2)
+    lists = [sorted(rs.choice(I, size=7, replace=False).tolist()) for _ in range(U)]      # 2 100 positives: 4.1 batches per epoch
+    smp = (EpochWalkSampler if kind == "epoch" else PhiloxSampler)(lists, I, seed=3).feeds(e)
+
+    def check(u, i, j, want_kind, tag):
+        loss = e.step(u, i, j).item()
+        assert e.lib.bprx_index_pass_kind(e.h) == want_kind, tag
+        want = o.step(u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy(), "sgd", lr, reg)
+        assert loss == pytest.approx(want, rel=2e-5), tag
+        for n in ("Gu", "Gi", "Bi"):
+            np.testing.assert_allclose(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rtol=2e-5, atol=2e-6, err_msg=tag)
+
+    for step in range(6):                                   # step 4 crosses the epoch boundary: two sampler calls, one batch
+        check(*smp.sample(B), 2, "%s step %d" % (kind, step))
+    a = smp.sample(B)
+    b = smp.sample(B)                                       # the planes now belong to b
+    check(*a, 1, "planes of another batch")
+    check(*b, 1, "planes dropped by the step in between")
+    check(*smp.sample(B - 8), 1, "B % 16 != 0")
+    check(*(torch.as_tensor(rs.randint(n, size=B).astype(np.int32), device="cuda") for n in (U, I, I)), 1, "caller's own batch")
+    check(*smp.sample(B), 2, "back on the planes")
+    e.sync_check()
