@@ -577,8 +577,8 @@ __global__ __launch_bounds__(NW * 64) void k_proj_bwd_bf16_v3(const uint16_t *__
 #pragma unroll
    for (int st = 0; st < PD; ++st) {                 // tiles past the end are all-zero: computed, harmless
     if (DB == 1) __syncthreads();                     // (DB == 2: the image of tile t+1 was last read for tile t-1, and every
-    BWD3_COMMIT(st, tile0 + st)                       //  wave has passed tile t's barrier since)
-    __syncthreads();
+    BWD3_COMMIT(st, tile0 + st)                       //  wave has passed tile t's barrier since.  Committing tile t+1 BEHIND tile
+    __syncthreads();                                  //  t's barrier, in one block with tile t's MFMAs, measured 2-4 % slower.)
     BWD3_ISSUE(st, tile0 + st + PD)
     const unsigned char *const Fs = Fs0 + (DB == 2 ? ((tile0 + st) & 1) * IMG : 0), *const Ws = Ws0 + (DB == 2 ? ((tile0 + st) & 1) * IMG : 0);
 #pragma unroll
@@ -1300,7 +1300,8 @@ int launch_bwd_rows(bprx_handle *h, int64_t bound, hipStream_t s) {
 // dE|dBp slabs = F^T W over the whole table: k_proj_bwd_bf16_v3 (W as bf16, conflict-free LDS image for the transpose reads).
 //   shape                                        instantiation                                      why
 //   bf16, <= 9 column tiles, D % 256 == 0        8 waves (256 columns), 3 tiles in flight           C2 / c4 shard: HBM-bound, deepest prefetch
-//   fp8, or > 9 column tiles                     8 waves, 2 tiles in flight, double-buffered LDS    MFMA-paced: one barrier per tile (c5, c2fp8)
+//   fp8, or > 9 column tiles                     8 waves, 2 tiles in flight, double-buffered LDS    MFMA-paced: one barrier per tile (c5, c2fp8);
+//                                                > 9 tiles: waves as a 4 x 2 grid (NS = 2)
 //   D % 256 != 0 (bf16)                          4 waves (128 columns), 2 tiles in flight           small / odd feature widths
 template <int NT>
 int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
@@ -1315,16 +1316,15 @@ int launch_bwd_nt(bprx_handle *h, hipStream_t s) {
   dim3 g3(D / (w8 ? 256 : 128), h->SK);
 #define BWD3_ARGS (const uint16_t *)h->Ft, I, D, (const uint16_t *)h->Wb, h->PS, h->part, rps3, 0, 1, (const int32_t *)nullptr, \
                   (const int32_t *)nullptr, (const float *)nullptr
-  static const int ns_env = getenv("BPRX_BWD_NS") ? atoi(getenv("BPRX_BWD_NS")) : 0;       // A/B: 1 = one wave column, 2 = two
-  const int ns = ns_env ? ns_env : (NT > 9 ? 2 : 1);
-  if constexpr (NT > 5) {
-    if (f8 && ns == 2) { launch_bwd3<NT, 32, 8, 2, true, false, 2, 2>(g3, s, BWD3_ARGS); return 0; }
-    if (!f8 && w8 && NT > 9 && ns == 2) { launch_bwd3<NT, 32, 8, 2, false, false, 2, 2>(g3, s, BWD3_ARGS); return 0; }
+  if constexpr (NT > 9) {        // wide projections: 4 x 2 wave grid (2 % on c5 / c5small / c5bf16; the kernel stays paced by
+    if (f8) { launch_bwd3<NT, 32, 8, 2, true, false, 2, 2>(g3, s, BWD3_ARGS); return 0; }          // issue, not by LDS volume)
+    if (w8) { launch_bwd3<NT, 32, 8, 2, false, false, 2, 2>(g3, s, BWD3_ARGS); return 0; }
   }
-  if (f8) launch_bwd3<NT, 32, 8, 2, true, false, 2>(g3, s, BWD3_ARGS);
-  else if (w8 && NT > 9) launch_bwd3<NT, 32, 8, 2, false, false, 2>(g3, s, BWD3_ARGS);
-  else if (w8) launch_bwd3<NT, 32, 8, 3, false, false, 1>(g3, s, BWD3_ARGS);
-  else launch_bwd3<NT, 32, 4, 2, false, false, 1>(g3, s, BWD3_ARGS);
+  if constexpr (NT <= 9) {
+    if (f8) { launch_bwd3<NT, 32, 8, 2, true, false, 2>(g3, s, BWD3_ARGS); return 0; }
+    if (w8) { launch_bwd3<NT, 32, 8, 3, false, false, 1>(g3, s, BWD3_ARGS); return 0; }
+  }
+  launch_bwd3<NT, 32, 4, 2, false, false, 1>(g3, s, BWD3_ARGS);
 #undef BWD3_ARGS
   return 0;
 }
