@@ -256,8 +256,9 @@ def main():
     # The triplet stream does not depend on the parameters, so the batch of step s+1 CAN be drawn on a side stream while
     # step s runs (--sampler-overlap: double-buffered index arrays, still one batch per step inside the timed region).
     pipe = batches is None and args.sampler_overlap
-    if batches is None and sharded is None and not pipe:
+    if batches is None and not pipe and (sharded is None or type(sharded).__name__ == "ReplicatedUserVBPR"):
         sampler.feeds(eng)                                # the sampler also leaves the byte planes the step's index pass scans
+                                                          # (the replicated-user step hands the same index arrays to its engine)
     if pipe:
         side = torch.cuda.Stream(device=device)
         bufs2 = (bufs, tuple(torch.empty(B, dtype=torch.int32, device=device) for _ in range(3)))

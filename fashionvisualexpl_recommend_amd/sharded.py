@@ -98,6 +98,8 @@ class ShardedVBPR:
         # a rank whose shard holds no positive still takes every step (with an empty batch: dist.ReplicatedUserVBPR.step)
         self.sampler = EpochWalkSampler(lists, self.hi - self.lo, device=self.engine.device,
                                         seed=getattr(params, "init_seed", 0) + 7919 * self.rank) if self.local_pos else None
+        if self.sampler is not None:
+            self.sampler.feeds(self.engine)                # (the step hands the sampler's index arrays to the engine unchanged)
         self.directory_parameters = f'batch_{params.batch_size}-D_{d}-K_{k}-lr_{params.lr}-reg_{params.reg}-W_{self.world}'
         # device CSRs with GLOBAL item ids for the shard-additive evaluation (the Evaluator's own helpers)
         ev = Evaluator(self, data, params.top_k)
