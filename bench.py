@@ -184,8 +184,6 @@ def main():
                 tables[n].copy_(hcopy)
             else:
                 dist.broadcast(tables[n], src=0)
-        if args.optimizer != "sgd" and args.dist_mode != "replicated":
-            raise SystemExit("multi-GPU bench: --optimizer adam_tf23 needs --dist-mode replicated")
         if args.dist_mode == "replicated":
             # users replicated on every rank (identical initial values: one generator seed for all ranks), items / F
             # sharded; ONE fixed-size all-gather per step (dist.ReplicatedUserVBPR)
@@ -203,15 +201,13 @@ def main():
             from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR
             sharded = ItemShardedVBPR(rank, world, users_total, tables["Gu"], tables["Tu"], tables["Gi"], tables["Bi"],
                                       tables["F"], tables["E"], tables["Bp"], lr=1e-4, reg=1e-4, max_batch=B,
-                                      feat_dtype=w["dtype"], device=local_rank)
+                                      feat_dtype=w["dtype"], device=local_rank, optimizer=args.optimizer)
         eng = sharded.eng
     elif world > 1 or force_sharded:
         # user-sharded BPRMF (configs[2]): user rows stay local, item rows are exchanged by all-to-all, no all-reduce
-        if args.optimizer != "sgd":
-            raise SystemExit("multi-GPU bench supports --optimizer sgd")
         from fashionvisualexpl_recommend_amd.dist import UserShardedBPRMF
         sharded = UserShardedBPRMF(rank, world, w["I"] * world, tables["Gu"], tables["Gi"], tables["Bi"], lr=1e-4, reg=1e-4,
-                                   max_batch=B, device=local_rank)
+                                   max_batch=B, device=local_rank, optimizer=args.optimizer)
         eng = sharded.eng
     else:
         eng = Engine(model=w["model"], num_users=w["U"], num_items=w["I"], embed_k=w["k"], embed_d=w["d"],

@@ -76,12 +76,13 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       CFAIL(BPRX_E_INVALID, "fp8 features need feat_dim %% 256 == 0 (got %d)", cfg->feat_dim);
     if (cfg->feat_dtype == BPRX_F_FP8 && !(cfg->feat_scale > 0.f)) CFAIL(BPRX_E_INVALID, "fp8 features need feat_scale > 0");
   }
-  if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->optimizer != BPRX_OPT_SGD)
-    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD supports optimizer sgd only");
-  if ((cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) && cfg->optimizer != BPRX_OPT_SGD &&
+  // exported gradients + adam_tf23: the handle takes the Adam steps of the rows it keeps; the exported side's owner applies its
+  // rows' steps (bprx_apply_user_msgs, or bprx_adam_rows over its shard).  A rank may see an empty batch and must still move
+  // every row it owns: the lazy form only (a sweep per step would have to run on ranks that launch nothing else).
+  if ((cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) && cfg->optimizer != BPRX_OPT_SGD &&
       ((getenv("BPRX_ADAM_LAZY") && atoi(getenv("BPRX_ADAM_LAZY")) == 0) ||
        (!getenv("BPRX_ADAM_LAZY") && (cfg->flags & BPRX_FLAG_ADAM_SWEEP) && !(cfg->flags & BPRX_FLAG_ADAM_LAZY))))
-    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_USER_GRAD with adam_tf23 needs the lazy form (BPRX_ADAM_LAZY != 0)");
+    CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_*_GRAD with adam_tf23 needs the lazy form (BPRX_ADAM_LAZY != 0)");
   if ((cfg->flags & BPRX_FLAG_EXPORT_ITEM_GRAD) && cfg->model != BPRX_MODEL_BPRMF)
     CFAIL(BPRX_E_INVALID, "BPRX_FLAG_EXPORT_ITEM_GRAD is for BPRMF (VBPR keeps its items and features local)");
   hipError_t e = hipSetDevice(cfg->device);
@@ -212,7 +213,7 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
     //  batches of 16 384 / 4 096 / 1 024, where the sweeps take 81-88 us: measured crossover between 16 384 and 4 096)
     const double chain_us = 20.0 * (double)cfg->num_users / (double)cfg->max_batch * 0.45;
     const double sweep_us = ((double)cfg->num_users * (cfg->embed_k + h->cfg.embed_d) + (double)cfg->num_items * (cfg->embed_k + 1)) * 24.0 / 4e6;
-    h->adam_lazy = (cfg->flags & BPRX_FLAG_EXPORT_USER_GRAD) ? true : chain_us < sweep_us;
+    h->adam_lazy = (cfg->flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD)) ? true : chain_us < sweep_us;
     if (cfg->flags & BPRX_FLAG_ADAM_SWEEP) h->adam_lazy = false;
     if (cfg->flags & BPRX_FLAG_ADAM_LAZY) h->adam_lazy = true;
     if (const char *e = getenv("BPRX_ADAM_LAZY")) h->adam_lazy = atoi(e) != 0;
@@ -404,7 +405,7 @@ extern "C" int bprx_step_begin_sparse(bprx_handle *h, const int32_t *user, const
     // A rank of a replicated-user multi-GPU step whose item shard holds no positive of this global batch: it contributes an
     // empty message and a zero dense gradient, but takes part in every collective and takes the same optimizer step as the
     // other replicas (bprx_pack_user_msg -> count 0, bprx_step_begin_dense -> dE|dBp = 0, bprx_apply_user_msgs, bprx_step_end).
-    if (!(h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD)) BPRX_FAIL(h, BPRX_E_INVALID, "step: empty batch");
+    if (!(h->cfg.flags & (BPRX_FLAG_EXPORT_USER_GRAD | BPRX_FLAG_EXPORT_ITEM_GRAD))) BPRX_FAIL(h, BPRX_E_INVALID, "step: empty batch");
     h->list_mode = 0; h->item_mode = 0;
     if (h->cfg.optimizer == BPRX_OPT_ADAM_TF23) {
       h->adam_t += 1;
@@ -664,6 +665,12 @@ extern "C" int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *o
   if (h->cfg.embed_k % 2 == 0 && h->cfg.embed_d % 2 == 0)
     return bprx_launch_score_gemm(h, u0, u1, out, s);          // fp32 MFMA GEMM (K step 2)
   return bprx_launch_score_block(h, u0, u1, out, s);
+}
+
+extern "C" int bprx_step_lr(const bprx_handle *h, float *lr_t) {
+  if (!h || !lr_t) return BPRX_E_INVALID;
+  *lr_t = h->pend_lr;
+  return BPRX_OK;
 }
 
 extern "C" int bprx_index_pass_kind(const bprx_handle *h) { return h ? h->idx_kind : 0; }

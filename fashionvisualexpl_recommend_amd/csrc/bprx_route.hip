@@ -161,9 +161,9 @@ extern "C" int bprx_route_reset(int32_t *send_idx, int64_t nslots, int32_t *curs
 
 extern "C" int bprx_route_plan(const int32_t *ids, int64_t n, int32_t rows_per_rank, int32_t nranks, int32_t cap, int32_t my_rank,
                                int32_t *slot, int32_t *send_idx, int32_t *cursor, int32_t *overflow, void *stream) {
-  if (!ids || !slot || !send_idx || !cursor || !overflow || n < 0 || rows_per_rank <= 0 || nranks <= 0 || nranks > RT_MAXW || cap <= 0)
+  if ((!ids && n) || !slot || !send_idx || !cursor || !overflow || n < 0 || rows_per_rank <= 0 || nranks <= 0 || nranks > RT_MAXW || cap <= 0)
     return BPRX_E_INVALID;
-  if (n == 0) return BPRX_OK;
+  if (n == 0) return BPRX_OK;                              // (an empty batch: nothing requested, the exchange still runs)
   hipLaunchKernelGGL(k_route_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, n, rows_per_rank,
                      nranks, cap, my_rank, slot, send_idx, cursor, overflow);
   return launched();

@@ -1724,6 +1724,20 @@ extern "C" int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 
+// One adam_tf23 step of a whole row shard from its summed gradient (g is returned to zero): what the OWNER of routed rows does
+// with the gradients the all-to-all brought back (bprx_route_scatter_add into g with scale 1).  The element function of the
+// handle's own sweeps and replays, so a sharded table moves bit for bit like an unsharded one given the same gradient sums.
+extern "C" int bprx_adam_rows(float *p, float *m, float *v, float *g, int64_t n, float lr_t, float beta1, float beta2, float eps,
+                              void *stream) {
+  if (!p || !m || !v || !g || n < 0) return BPRX_E_INVALID;
+  if (n == 0) return BPRX_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_adam_sparse, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, (size_t)n, beta1, beta2,
+                     lr_t, eps);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}
+
 // ---- replicated-user multi-GPU step: message packing / application (include/bprx.h) ----
 namespace {
 // msg (4-byte words): [count,0,0,0 | ids[cap4] | cap*k dGu rows | cap*d dTu rows | D*d + D dense gradient], cap4 = cap
@@ -2179,7 +2193,8 @@ int bprx_launch_apply(bprx_handle *h, const int32_t *u, const int32_t *i, const 
     const bool vec = vec_ok(h);
     const int G = pick_group(a.k, a.d, vec);
     const int fk = (h->cfg.flags & BPRX_FLAG_EXPORT_USER_GRAD) ? 1 : 0;      // replicated multi-GPU: users via bprx_apply_user_msgs
-    const int ek = h->item_mode ? 1 : 3;                                     // segments: k_item_seg took the items' steps
+    const int ek = (h->item_mode || (h->cfg.flags & BPRX_FLAG_EXPORT_ITEM_GRAD)) ? 1 : 3;   // segments: k_item_seg took the items' steps;
+                                                                             // exported item gradients: their owner does
     const AdamTables T = make_adam_tables(h);
     const AdamLazy al = {b1, b2, eps, h->lr_hist};
     if (ek > fk)

@@ -13,7 +13,8 @@ Partitioning
          overlaps nothing the next step needs before its own fetch.
 
 The global step is exactly the single-GPU batch-synchronous step on the concatenation of all ranks' batches
-(tests/test_gpu_dist.py checks that against the CPU oracle with two ranks).  sgd only in this mode.
+(tests/test_gpu_dist.py checks that against the CPU oracle with two ranks).  sgd, or adam_tf23: the engine steps the rows it
+keeps and E|Bp, the owners of the routed rows step their whole shard from the summed returned gradients (bprx_adam_rows).
 """
 import torch
 import torch.distributed as dist
@@ -226,23 +227,33 @@ class ItemShardedVBPR:
     """Per-rank driver of the item-sharded VBPR step (see module docstring)."""
 
     def __init__(self, rank, world, users_total, Gu_shard, Tu_shard, Gi_shard, Bi_shard, F_shard, E, Bp, lr, reg,
-                 max_batch, feat_dtype="bf16", group=None, device=None, fixed_cap=True, slack=2.0):
+                 max_batch, feat_dtype="bf16", group=None, device=None, fixed_cap=True, slack=2.0, optimizer="sgd"):
         """fixed_cap (default): the row exchange uses equal, fixed-capacity splits (UserRowExchange.plan_fixed): no host
-        synchronisation inside the step; False: exact data-dependent splits (one `.cpu()` of the split sizes per step)."""
-        from .engine import Engine, scatter_add
-        self._scatter_add = scatter_add
+        synchronisation inside the step; False: exact data-dependent splits (one `.cpu()` of the split sizes per step).
+        optimizer: 'sgd' | 'adam_tf23' (native fixed-capacity path): the engine takes the Adam steps of its item rows and of
+        E|Bp; the returned user-row gradients are summed into a gradient table of the owner's shard, and the owner takes the
+        Adam step of its WHOLE shard (bprx_adam_rows: TF-2.3's Adam moves every row every step)."""
+        from .engine import Engine, scatter_add, adam_rows
+        self._scatter_add, self._adam_rows = scatter_add, adam_rows
         self.rank, self.world, self.group = rank, world, group
         self.lr = lr
         self.fixed_cap = fixed_cap
+        self.adam = optimizer == "adam_tf23"
+        if optimizer not in ("sgd", "adam_tf23"):
+            raise ValueError("optimizer: 'sgd' | 'adam_tf23'")
+        if self.adam and not fixed_cap:
+            raise NotImplementedError("adam_tf23 in the all-to-all mode: the native fixed-capacity exchange only")
         self.cap = int(min(max_batch, -(-max_batch // world) * slack + 8))
         self.x = UserRowExchange(rank, world, users_total, group)
         k, d = Gu_shard.shape[1], Tu_shard.shape[1]
         self.eng = Engine(model="vbpr", num_users=max_batch, num_items=Gi_shard.shape[0], embed_k=k, embed_d=d,
-                          feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer="sgd", lr=lr, reg=reg,
+                          feat_dim=F_shard.shape[1], feat_dtype=feat_dtype, optimizer=optimizer, lr=lr, reg=reg,
                           max_batch=max_batch, device=device, export_user_grad=True)
         dev = self.eng.device
         self.Gu_shard = Gu_shard.to(dev).contiguous()
         self.Tu_shard = Tu_shard.to(dev).contiguous()
+        if self.adam:                                            # the owner's Adam state: moments + the summed gradients of a step
+            self.adam_state = {n: tuple(torch.zeros_like(t) for _ in range(3)) for n, t in (("Gu", self.Gu_shard), ("Tu", self.Tu_shard))}
         self.stage_Gu = torch.zeros((max_batch, k), dtype=torch.float32, device=dev)
         self.stage_Tu = torch.zeros((max_batch, d), dtype=torch.float32, device=dev)
         self.eng.bind(Gu=self.stage_Gu, Gi=Gi_shard, Bi=Bi_shard, Tu=self.stage_Tu, F=F_shard, E=E, Bp=Bp)
@@ -304,7 +315,14 @@ class ItemShardedVBPR:
         self._dense_allreduce()
         loss = self.eng.step_end(want_loss=want_loss)
         dG, dT = self.eng.user_grad()
-        self.x.give_back_native(dG, dT, ridx, self.Gu_shard, self.Tu_shard, -self.lr)      # (also re-zeroes the gradient rows)
+        if self.adam:
+            (mG, vG, gG), (mT, vT, gT) = self.adam_state["Gu"], self.adam_state["Tu"]
+            self.x.give_back_native(dG, dT, ridx, gG, gT, 1.0)                               # summed gradients of my users' rows
+            lr_t = self.eng.step_lr()
+            self._adam_rows(self.Gu_shard, mG, vG, gG, lr_t)
+            self._adam_rows(self.Tu_shard, mT, vT, gT, lr_t)
+        else:
+            self.x.give_back_native(dG, dT, ridx, self.Gu_shard, self.Tu_shard, -self.lr)  # (also re-zeroes the gradient rows)
         self.eng.clear_user_marks(B)
         return loss
 
@@ -456,26 +474,35 @@ class UserShardedBPRMF:
     batch's positive and negative items are fetched from / their gradients returned to the item owners by all-to-all
     (staging row b = positive item of triplet b, row B+b = its negative item; BPRX_FLAG_EXPORT_ITEM_GRAD).
     No dense parameter, hence no all-reduce at all.  The global step equals the single-GPU batch-synchronous step on the
-    concatenation of all ranks' batches.  sgd only."""
+    concatenation of all ranks' batches.  sgd, or adam_tf23 (see __init__)."""
 
     def __init__(self, rank, world, items_total, Gu_shard, Gi_shard, Bi_shard, lr, reg, max_batch, group=None, device=None,
-                 fixed_cap=True, slack=2.0):
+                 fixed_cap=True, slack=2.0, optimizer="sgd"):
         """fixed_cap (default): the row exchange uses equal, fixed-capacity splits (RowExchange.plan_fixed: 2B requested rows
         spread over `world` owners, `slack` x the even share per owner): no host synchronisation inside the step, an
         overflowing bucket raises a device flag (x.overflowed()); False: exact data-dependent splits (one `.cpu()` of the
         split sizes per step)."""
-        from .engine import Engine, scatter_add
-        self._scatter_add = scatter_add
+        from .engine import Engine, scatter_add, adam_rows
+        self._scatter_add, self._adam_rows = scatter_add, adam_rows
         self.rank, self.world, self.group, self.lr = rank, world, group, lr
         self.fixed_cap = fixed_cap
+        # adam_tf23 (native fixed-capacity path): the engine (lazy form) steps the user rows; the item owners sum the returned
+        # gradients into a gradient table of their shard and step the WHOLE shard (bprx_adam_rows), every global step
+        self.adam = optimizer == "adam_tf23"
+        if optimizer not in ("sgd", "adam_tf23"):
+            raise ValueError("optimizer: 'sgd' | 'adam_tf23'")
+        if self.adam and not fixed_cap:
+            raise NotImplementedError("adam_tf23 in the all-to-all mode: the native fixed-capacity exchange only")
         self.cap = int(min(2 * max_batch, -(-2 * max_batch // world) * slack + 8))
         self.x = RowExchange(rank, world, items_total, group)
         k = Gu_shard.shape[1]
-        self.eng = Engine(model="bprmf", num_users=Gu_shard.shape[0], num_items=2 * max_batch, embed_k=k, optimizer="sgd",
+        self.eng = Engine(model="bprmf", num_users=Gu_shard.shape[0], num_items=2 * max_batch, embed_k=k, optimizer=optimizer,
                           lr=lr, reg=reg, max_batch=max_batch, device=device, export_item_grad=True)
         dev = self.eng.device
         self.Gi_shard = Gi_shard.to(dev).float().contiguous()                  # [Ish, k]
         self.Bi_col = Bi_shard.to(dev).float().reshape(-1, 1).contiguous()      # [Ish, 1]
+        if self.adam:
+            self.adam_state = {n: tuple(torch.zeros_like(t) for _ in range(3)) for n, t in (("Gi", self.Gi_shard), ("Bi", self.Bi_col))}
         self.stage_Gi = torch.zeros((2 * max_batch, k), dtype=torch.float32, device=dev)
         self.stage_Bi = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
         self.eng.bind(Gu=Gu_shard, Gi=self.stage_Gi, Bi=self.stage_Bi)
@@ -503,11 +530,18 @@ class UserShardedBPRMF:
             ridx = self.x.plan_native(items)
             self.x.fetch_native(self.Gi_shard, self.Bi_col, ridx, self.stage_Gi, self.stage_Bi)
             loss = None
-            if B:
+            if B or self.adam:                                   # (adam: an empty batch is still a step -- every row moves)
                 loss = self.eng.step(u_local, self.iota[:B], self.iota[B:2 * B], want_loss=want_loss, loss_out=loss_out,
                                      loss_index=loss_index)
             dG, dB = self.eng.item_grad()
-            self.x.give_back_native(dG, dB.view(-1, 1), ridx, self.Gi_shard, self.Bi_col, -self.lr)   # (re-zeroes dG / dB rows)
+            if self.adam:
+                (mG, vG, gG), (mB, vB, gB) = self.adam_state["Gi"], self.adam_state["Bi"]
+                self.x.give_back_native(dG, dB.view(-1, 1), ridx, gG, gB, 1.0)                       # summed gradients of my items' rows
+                lr_t = self.eng.step_lr()
+                self._adam_rows(self.Gi_shard, mG, vG, gG, lr_t)
+                self._adam_rows(self.Bi_col, mB, vB, gB, lr_t)
+            else:
+                self.x.give_back_native(dG, dB.view(-1, 1), ridx, self.Gi_shard, self.Bi_col, -self.lr)   # (re-zeroes dG / dB rows)
             self.eng.clear_item_marks(2 * B)
             return loss
         items = torch.cat([i_global, j_global])                                   # 2B requested rows

@@ -165,6 +165,12 @@ class Engine:
         _ffi.check(self.h, self.lib.bprx_step(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), lp, _stream()))
         return self._loss if loss_out is None else loss_out
 
+    def step_lr(self):
+        """The bias-corrected learning rate of the step begun last (bprx_step_lr; sgd: lr)."""
+        v = C.c_float()
+        _ffi.check(self.h, self.lib.bprx_step_lr(self.h, C.byref(v)))
+        return v.value
+
     def step_begin(self, user, pos, neg):
         _ffi.check(self.h, self.lib.bprx_step_begin(self.h, _ptr(user), _ptr(pos), _ptr(neg), user.numel(), _stream()))
 
@@ -310,6 +316,16 @@ def scatter_add(table, idx, rows, scale):
     rc = lib.bprx_scatter_add(_ptr(table), table.shape[0], ncols, _ptr(idx), _ptr(rows), idx.numel(), float(scale), _stream())
     if rc < 0:
         raise _ffi.BprxError(rc, "bprx_scatter_add failed")
+
+
+def adam_rows(p, m, v, g, lr_t, beta1=0.9, beta2=0.999, eps=1e-7):
+    """One adam_tf23 step of a whole row shard from its summed gradient table g (returned to zero): bprx_adam_rows."""
+    lib = _ffi.lib()
+    assert all(t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel() for t in (p, m, v, g))
+    rc = lib.bprx_adam_rows(_ptr(p), _ptr(m), _ptr(v), _ptr(g), p.numel(), float(lr_t), float(beta1), float(beta2), float(eps),
+                            _stream())
+    if rc < 0:
+        raise _ffi.BprxError(rc, "bprx_adam_rows failed")
 
 
 class _DevView:

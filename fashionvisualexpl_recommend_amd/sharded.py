@@ -272,21 +272,20 @@ class ShardedVBPR:
 
 class ShardedBPRMF:
     """User-sharded BPRMF behind the reference's model surface (BASELINE.json configs[2]; train_rec --world_size N --shard user
-    --rec bprmf --optimizer sgd).  Rank r owns the users [r*ush, (r+1)*ush) -- their Gu rows, their training positives, their
+    --rec bprmf).  Rank r owns the users [r*ush, (r+1)*ush) -- their Gu rows, their training positives, their
     evaluation -- and the item rows [r*ish, (r+1)*ish) of Gi / Bi.  A step fetches the rows of the batch's positive and negative
     items from their owners and returns their gradients by fixed-capacity all-to-alls (dist.UserShardedBPRMF: routing in HIP
     kernels, no host synchronisation); negatives are drawn from ALL items, as the reference does (dataset.py:101).
     Evaluation: the item shards are all-gathered once per epoch, every rank scores and evaluates ITS users on the device
     (bprx_score_block + bprx_eval_users), and the per-user rows are gathered in user order -- the means equal the single-GPU
-    evaluator's.  Rank 0 writes the reference's outputs (BPRMF.py:152-183).  sgd only (the all-to-all modes apply the routed
-    gradient rows with a scatter-add at the owners)."""
+    evaluator's.  Rank 0 writes the reference's outputs (BPRMF.py:152-183).  --optimizer sgd: the owners add the routed gradient
+    rows into their shard; adam_tf23 (the reference's optimizer): they sum them into a gradient table and take the Adam step of
+    the whole shard (dist.UserShardedBPRMF)."""
 
     def __init__(self, data, params, group=None):
         from .dist import UserShardedBPRMF, shard_size
         from .engine import Engine, EpochWalkSampler
         from .evaluator import Evaluator
-        if getattr(params, "optimizer", "sgd") != "sgd":
-            raise NotImplementedError("--shard user: --optimizer sgd (the all-to-all modes have no adam_tf23 form)")
         self.data, self.params, self.group = data, params, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.num_users, self.num_items = data.num_users, data.num_items
@@ -303,7 +302,7 @@ class ShardedBPRMF:
         # (shards are padded to the full shard size: the row routing addresses rows_per_rank = ish rows on every rank)
         self.m = UserShardedBPRMF(self.rank, self.world, self.num_items, c(pad_rows(Gu[self.u0:self.u1], nu)),
                                   c(pad_rows(Gi[self.i0:self.i1], self.ish)), c(np.zeros(self.ish, np.float32)), params.lr, params.reg,
-                                  max_batch=self.batch, group=group)
+                                  max_batch=self.batch, group=group, optimizer=getattr(params, "optimizer", "sgd"))
         self.engine = self.m.eng
         dev = self.engine.device
         self.host_staged = dist.get_backend(group) != "nccl"

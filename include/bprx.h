@@ -74,7 +74,7 @@ typedef struct {
                             features, visual_loader_mixin.py:30); ignored otherwise */
 } bprx_config;
 
-/* BPRX_FLAG_EXPORT_USER_GRAD (item-sharded multi-GPU, sgd only): the bound Gu/Tu are per-step STAGING rows fetched from
+/* BPRX_FLAG_EXPORT_USER_GRAD (item-sharded multi-GPU; with adam_tf23 see bprx_adam_rows): the bound Gu/Tu are per-step STAGING rows fetched from
    their owner ranks (row b = the user row of triplet b); the step leaves their summed gradients in the buffers of
    bprx_user_grad() instead of applying them, and the caller routes those rows back to the owners
    (bprx_scatter_add with scale = -lr) and clears them with bprx_clear_user_grad(). */
@@ -87,7 +87,7 @@ enum { BPRX_FLAG_EXPORT_USER_GRAD = 1, BPRX_FLAG_EXPORT_ITEM_GRAD = 2, BPRX_FLAG
    part; the caller all-reduces (sum, RCCL) the buffer of bprx_dense_grad() between bprx_pack_user_msg and bprx_step_end --
    the "RCCL all-reduce on E / beta'" form of SURVEY 8(e).  Without it dE|dBp rides in the all-gathered message and is summed
    in rank order (bit-identical replicas whatever the collective's reduction order). */
-/* BPRX_FLAG_EXPORT_ITEM_GRAD (user-sharded multi-GPU BPRMF, sgd only): the mirror image -- the bound Gi/Bi are per-step
+/* BPRX_FLAG_EXPORT_ITEM_GRAD (user-sharded multi-GPU BPRMF; with adam_tf23 see bprx_adam_rows): the mirror image -- the bound Gi/Bi are per-step
    STAGING rows fetched from the item owners (row b = the positive item row of triplet b, row B+b its negative item row);
    their gradients are left in the buffers of bprx_item_grad() and cleared with bprx_clear_item_grad(). */
 
@@ -195,6 +195,17 @@ BPRX_API int64_t bprx_user_msg_floats(const bprx_handle *h, int64_t cap);
 BPRX_API int bprx_pack_user_msg(bprx_handle *h, const int32_t *user, int64_t B, int64_t cap, float *msg, void *stream);
 BPRX_API int bprx_apply_user_msgs(bprx_handle *h, const float *msgs, int32_t nranks, int64_t cap, float scale, void *stream);
 BPRX_API int bprx_sum_dense_parts(bprx_handle *h, const float *parts, int32_t nranks, void *stream);
+/* adam_tf23 in the all-to-all modes: the handle (lazy form) takes the Adam steps of the rows it keeps and of E|Bp; the rows whose
+   gradients it exports are stepped by their OWNER rank, over its whole shard (TF-2.3's Adam is not lazy: every row decays and
+   moves every step, BPRMF.py:123 / VBPR.py:142): the owner adds the returned gradient rows into a zero gradient table
+   (bprx_route_scatter_add, scale 1) and calls
+     bprx_adam_rows  p, m, v, g: n floats each (the shard, its two moment tables, the gradient table: returned to zero);
+                     lr_t from bprx_step_lr of this step -- every rank steps every global step (an empty batch is a step with
+                     B = 0), so all ranks hold the same step count;
+     bprx_step_lr    the bias-corrected learning rate of the step begun last (sgd: lr). */
+BPRX_API int bprx_adam_rows(float *p, float *m, float *v, float *g, int64_t n, float lr_t, float beta1, float beta2, float eps,
+                            void *stream);
+BPRX_API int bprx_step_lr(const bprx_handle *h, float *lr_t);
 BPRX_API int bprx_item_grad(bprx_handle *h, float **dGi, float **dBi);
 BPRX_API int bprx_clear_item_grad(bprx_handle *h, int64_t n_rows, int32_t marks_only, void *stream);
 BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, const int32_t *idx, const float *rows,

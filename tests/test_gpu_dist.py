@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dtype):
+def _worker(rank, world, port, dtype, opt="sgd"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -28,7 +28,7 @@ def _worker(rank, world, port, dtype):
         from fashionvisualexpl_recommend_amd.dist import ItemShardedVBPR, shard_size
         from oracle import oracle as orc
         torch.cuda.set_device(0)
-        U, I, k, d, D, B, lr, reg = 45, 64, 8, 20, 256, 96, 0.05, 1e-3
+        U, I, k, d, D, B, lr, reg = 45, 64, 8, 20, 256, 96, (0.05 if opt == "sgd" else 0.01), 1e-3
         ush, ish = shard_size(U, world), I // world
         rs = np.random.RandomState(1)
         F = synth.make_features(I, D, seed=1)
@@ -41,24 +41,30 @@ def _worker(rank, world, port, dtype):
         us, it = slice(rank * ush, min(U, (rank + 1) * ush)), slice(rank * ish, (rank + 1) * ish)
         c = lambda a: torch.as_tensor(a.copy())
         m = ItemShardedVBPR(rank, world, U, c(t["Gu"][us]), c(t["Tu"][us]), c(t["Gi"][it]), c(t["Bi"][it]), c(t["F"][it]),
-                            c(t["E"]), c(t["Bp"]), lr, reg, max_batch=B, feat_dtype=dtype, device=0)
+                            c(t["E"]), c(t["Bp"]), lr, reg, max_batch=B, feat_dtype=dtype, device=0, optimizer=opt)
         o = orc.OracleModel(**t, quant=1 if dtype == "bf16" else 0)
-        for step in range(3):
+        for step in range(3 if opt == "sgd" else 5):
             batches = []
             for r in range(world):                        # every rank knows every batch (test only) to feed the oracle
                 br = np.random.RandomState(100 + step * world + r)
                 nb = B - 10 * r                           # ragged
+                if opt != "sgd" and step == 1 and r == 1:
+                    nb = 0                                 # adam: an empty batch is still a step (every row moves)
                 batches.append((br.randint(U, size=nb).astype(np.int32), br.randint(ish, size=nb).astype(np.int32),
                                 br.randint(ish, size=nb).astype(np.int32)))
+            if opt != "sgd" and step >= 2:                # adam: users that appear in nobody's batch keep moving all the same
+                batches = [(b[0] % (10 + 7 * r) + 20 * r, b[1], b[2]) for r, b in enumerate(batches)]
             u, i, j = batches[rank]
             dev = lambda a: torch.as_tensor(a, device="cuda")
             m.step(dev(u), dev(i), dev(j))
             gu = np.concatenate([b[0] for b in batches])
             gi = np.concatenate([b[1] + r * ish for r, b in enumerate(batches)])
             gj = np.concatenate([b[2] + r * ish for r, b in enumerate(batches)])
-            o.step(gu, gi, gj, "sgd", lr, reg)
+            o.step(gu, gi, gj, opt, lr, reg)
         m.eng.sync_check()
         rt, at = (2e-5, 2e-6) if dtype == "fp32" else (2e-3, 1e-4)
+        if opt != "sgd":
+            at = max(at, 2e-3 * lr)                        # see test_gpu_parity.test_bprmf_steps_match_oracle
         chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=rt, atol=at, err_msg=n)
         chk(m.Gu_shard, o.Gu[us], "Gu shard")
         chk(m.Tu_shard, o.Tu[us], "Tu shard")
@@ -79,7 +85,14 @@ def test_item_sharded_vbpr_two_ranks_match_oracle(dtype):
     mp.spawn(_worker, args=(2, _free_port(), dtype), nprocs=2, join=True)
 
 
-def _worker_bprmf(rank, world, port, fixed_cap=True):
+def test_item_sharded_vbpr_two_ranks_adam_tf23_match_oracle():
+    """The reference's optimizer through the all-to-all mode: the engine (lazy form) steps its item rows and E|Bp, the owners
+    of the user rows take the Adam step of their whole shard from the summed returned gradients (bprx_adam_rows) -- including
+    a step in which one rank's batch is empty and users that nobody touches for several steps."""
+    mp.spawn(_worker, args=(2, _free_port(), "fp32", "adam_tf23"), nprocs=2, join=True)
+
+
+def _worker_bprmf(rank, world, port, fixed_cap=True, opt="sgd"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -87,7 +100,7 @@ def _worker_bprmf(rank, world, port, fixed_cap=True):
         from fashionvisualexpl_recommend_amd.dist import UserShardedBPRMF, shard_size
         from oracle import oracle as orc
         torch.cuda.set_device(0)
-        U, I, k, B, lr, reg = 60, 75, 16, 128, 0.05, 1e-3
+        U, I, k, B, lr, reg = 60, 75, 16, 128, (0.05 if opt == "sgd" else 0.01), 1e-3
         ush, ish = U // world, shard_size(I, world)
         rs = np.random.RandomState(2)
         t = dict(Gu=synth.glorot_uniform(rs, U, k), Gi=synth.glorot_uniform(rs, I, k),
@@ -95,30 +108,33 @@ def _worker_bprmf(rank, world, port, fixed_cap=True):
         us, it = slice(rank * ush, (rank + 1) * ush), slice(rank * ish, min(I, (rank + 1) * ish))
         c = lambda a: torch.as_tensor(a.copy())
         m = UserShardedBPRMF(rank, world, I, c(t["Gu"][us]), c(t["Gi"][it]), c(t["Bi"][it]), lr, reg, max_batch=B, device=0,
-                             fixed_cap=fixed_cap)
+                             fixed_cap=fixed_cap, optimizer=opt)
         o = orc.OracleModel(**t)
-        for step in range(3):
+        for step in range(3 if opt == "sgd" else 5):
             batches = []
             for r in range(world):
                 br = np.random.RandomState(200 + step * world + r)
                 nb = B - 17 * r
+                if opt != "sgd" and step == 1 and r == 1:
+                    nb = 0                                 # adam: an empty batch is still a step (every row moves)
                 batches.append((br.randint(ush, size=nb).astype(np.int32), br.randint(I, size=nb).astype(np.int32),
                                 br.randint(I, size=nb).astype(np.int32)))
+            if opt != "sgd" and step >= 2:                # adam: items and users nobody touches for several steps keep moving
+                batches = [(b[0] % 11, b[1] % 40, b[2] % 40) for b in batches]
+            for b in batches:
+                if b[0].size:
+                    b[1][:4] = 7                           # the same remote/local item several times, also as negative
+                    b[2][4:6] = 7
             u, i, j = batches[rank]
-            i[:4] = 7                                      # the same remote/local item several times, also as negative
-            j[4:6] = 7
             dev = lambda a: torch.as_tensor(a, device="cuda")
             m.step(dev(u), dev(i), dev(j))
-            for r, b in enumerate(batches):
-                if r != rank:
-                    b[1][:4] = 7
-                    b[2][4:6] = 7
             o.step(np.concatenate([b[0] + r * ush for r, b in enumerate(batches)]), np.concatenate([b[1] for b in batches]),
-                   np.concatenate([b[2] for b in batches]), "sgd", lr, reg)
+                   np.concatenate([b[2] for b in batches]), opt, lr, reg)
         m.eng.sync_check()
         if fixed_cap:
             assert not m.x.overflowed()
-        chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
+        at = 2e-6 if opt == "sgd" else 2e-3 * lr
+        chk = lambda got, want, n: np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=at, err_msg=n)
         chk(m.eng.t["Gu"], o.Gu[us], "Gu shard")
         chk(m.Gi_shard, o.Gi[it], "Gi shard")
         chk(m.Bi_shard, o.Bi[it], "Bi shard")
@@ -130,6 +146,12 @@ def _worker_bprmf(rank, world, port, fixed_cap=True):
 def test_user_sharded_bprmf_two_ranks_match_oracle(fixed_cap):
     """fixed_cap: equal, fixed-capacity all-to-all splits (no host synchronisation inside the step); False: exact splits."""
     mp.spawn(_worker_bprmf, args=(2, _free_port(), fixed_cap), nprocs=2, join=True)
+
+
+def test_user_sharded_bprmf_two_ranks_adam_tf23_match_oracle():
+    """adam_tf23 through the user-sharded all-to-all mode (the CLI's default optimizer with --shard user): the engine steps
+    the user rows, the item owners step their whole Gi / Bi shard from the summed returned gradients."""
+    mp.spawn(_worker_bprmf, args=(2, _free_port(), True, "adam_tf23"), nprocs=2, join=True)
 
 
 def _worker_replicated(rank, world, port, dtype, opt="sgd", dense_reduce="gather", overlap=True):
@@ -376,14 +398,14 @@ def test_train_rec_cli_rank_without_local_positives(tmp_path):
     mp.spawn(_worker_cli, args=(2, _free_port(), str(tmp_path), "half", 2, False), nprocs=2, join=True)
 
 
-def _worker_cli_user(rank, world, port, root):
+def _worker_cli_user(rank, world, port, root, opt="sgd", lr="0.15"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), BPRX_ONE_GPU="1")
     from fashionvisualexpl_recommend_amd import train_rec
     epochs = 8
     out = train_rec.train(["--dataset", "ush", "--rec", "bprmf", "--world_size", str(world), "--shard", "user",
                            "--dist_backend", "gloo", "--batch_size", "128", "--epochs", str(epochs), "--embed_k", "16",
-                           "--lr", "0.15", "--top_k", "10", "--optimizer", "sgd", "--verbose", "2",
+                           "--lr", lr, "--top_k", "10", "--optimizer", opt, "--verbose", "2",
                            "--data_root", root, "--results_root", os.path.join(root, "res")])
     try:
         from argparse import Namespace
@@ -420,13 +442,15 @@ def _worker_cli_user(rank, world, port, root):
         dist.destroy_process_group()
 
 
-def test_train_rec_cli_user_sharded_two_ranks(tmp_path):
+@pytest.mark.parametrize("opt,lr", [("sgd", "0.15"), ("adam_tf23", "0.02")])
+def test_train_rec_cli_user_sharded_two_ranks(tmp_path, opt, lr):
     """train_rec.py --world_size 2 --shard user --rec bprmf: user rows stay on their rank, item rows travel by the fixed-capacity
-    all-to-alls (routing in HIP kernels), every rank evaluates its own users on the device; the reference's outputs from rank 0."""
+    all-to-alls (routing in HIP kernels), every rank evaluates its own users on the device; the reference's outputs from rank 0.
+    adam_tf23 is the CLI's default optimizer (the reference's): the item owners step their whole shard (bprx_adam_rows)."""
     from fashionvisualexpl_recommend_amd import synth
     tr, va, te = synth.make_interactions_clustered(301, 240, per_user=22, clusters=12, seed=5)      # 301: unequal user shards
     synth.write_dataset(str(tmp_path), "ush", tr, va, te, 240)
-    mp.spawn(_worker_cli_user, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_cli_user, args=(2, _free_port(), str(tmp_path), opt, lr), nprocs=2, join=True)
 
 
 def _worker_nosync(rank, world, port):
