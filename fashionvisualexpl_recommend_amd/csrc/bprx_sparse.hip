@@ -42,6 +42,8 @@ struct SparseArgs {
   const int32_t *seg_rank;   // [2B] rank of occurrence (role*B + b) within its item
   const int32_t *seg_ptr;    // [I]  first entry of the item's segment
   int2 *seg_ent;             // [2B] {user key | role << 31, g_b}; the key indexes the rows below
+  int seg_ent_cap;           // entries the buffer holds (stores are bounded: ranks from byte planes that do not belong to the
+                             // index arrays -- a caller that changed them after sampling -- must not write outside it)
   const float *uG, *uT;      // PRE-update user rows as k_item_seg gathers them: the tables (key = user id), or the batch's
   int usG, usT;              //   uold rows (key = user slot; k_triplet_seg mode 0); row strides in floats
   int32_t *hot_done;         // [I]  finished chunks of a hot item (k_item_seg's last-finisher hand-off), all-zero between steps
@@ -1333,8 +1335,8 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
   if (lane == 0 && valid) {
     a.lossb[b] = sp + reg * (nrm + bi * bi + bj * bj * 0.1f);          // BPRMF.py:108-112 / VBPR.py:121-126
     const int key = su.mode == 0 ? slot : u;                           // where k_item_seg finds the pre-update user row
-    a.seg_ent[spI] = make_int2(key, __float_as_int(g));
-    a.seg_ent[spJ] = make_int2((int)((unsigned)key | 0x80000000u), __float_as_int(g));
+    if ((unsigned)spI < (unsigned)a.seg_ent_cap) a.seg_ent[spI] = make_int2(key, __float_as_int(g));
+    if ((unsigned)spJ < (unsigned)a.seg_ent_cap) a.seg_ent[spJ] = make_int2((int)((unsigned)key | 0x80000000u), __float_as_int(g));
   }
   // ---- user side: per-occurrence gradient rows -> LDS, runs summed in order ----
   float *row = rows + tl * kd;
@@ -1631,7 +1633,7 @@ SparseArgs make_args(bprx_handle *h, const float *P) {
     // side may therefore not be updated in place either (staging + k_apply_sgd)
     a.fastI = 0; a.fastU = 0; a.fast = 0;
   }
-  a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.hot_done = h->hot_done;
+  a.seg_rank = h->seg_rank; a.seg_ptr = h->seg_ptr; a.seg_ent = (int2 *)h->seg_ent; a.seg_ent_cap = (int)h->seg_ent_cap; a.hot_done = h->hot_done;
   a.seg_lead = (const int4 *)h->seg_lead; a.seg_lead_cap = (int)h->seg_lead_cap;
   a.seg_nlead = h->seg_cursor ? h->seg_cursor + 3 * h->seg_cur_slot + 1 : nullptr;
   a.ulist = h->ulist; a.ulist_n = h->seg_cursor ? h->seg_cursor + 3 * h->seg_cur_slot + 2 : nullptr;
