@@ -87,11 +87,11 @@ def lib():
         "bprx_clear_item_grad": (C.c_int, [vp, i64, i32, vp]),
         "bprx_scatter_add": (C.c_int, [vp, i32, i32, vp, vp, i64, f32, vp]),
         "bprx_route_reset": (C.c_int, [vp, i64, vp, i32, vp]),
-        "bprx_route_plan": (C.c_int, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
-        "bprx_route_gather": (C.c_int, [vp, i32, vp, i32, i32, vp, i64, vp, vp]),
+        "bprx_route_plan": (C.c_int, [vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "bprx_route_gather": (C.c_int, [vp, i32, vp, i32, i32, vp, i64, vp, vp, vp]),
         "bprx_route_unpack": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, i32, vp]),
-        "bprx_route_pack": (C.c_int, [vp, i32, vp, i32, vp, i64, vp, vp, vp, i32, f32, vp]),
-        "bprx_route_scatter_add": (C.c_int, [vp, i32, vp, i32, i32, vp, vp, i64, f32, vp]),
+        "bprx_route_pack": (C.c_int, [vp, i32, vp, i32, vp, i64, vp, vp, vp, i32, f32, vp, vp, i64, vp, i32, vp]),
+        "bprx_route_scatter_add": (C.c_int, [vp, i32, vp, i32, i32, vp, vp, i64, f32, vp, vp]),
         "bprx_score_block": (C.c_int, [vp, i32, i32, vp, vp]),
         "bprx_eval_users": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
         "bprx_topk": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),

@@ -139,7 +139,12 @@ class UserRowExchange:
         ps = (int(width) + 3) & ~3                                # routed rows are padded to whole 16-byte pieces
         self._nat = dict(lib=_ffi.lib(), cap=int(cap), width=int(width), send_idx=i32(W * cap), cursor=i32(W), overflow=i32(1),
                          slot=i32(n_max), rows_out=torch.zeros((W * cap, ps), dtype=torch.float32, device=device),
-                         grad_out=torch.zeros((W * cap, ps), dtype=torch.float32, device=device))
+                         grad_out=torch.zeros((W * cap, ps), dtype=torch.float32, device=device),
+                         # row multiplicities (own requests / the other ranks' requests): a row that occurs once is added
+                         # without float atomics; the kernels leave both arrays all-zero again (bprx_route.hip)
+                         own_cnt=i32(self.ush), cnt=i32(self.ush))
+        nat = self._nat
+        self._rc(nat["lib"].bprx_route_reset(self._p(nat["send_idx"]), W * nat["cap"], self._p(nat["cursor"]), W, self._s()), "route_reset")
 
     @staticmethod
     def _p(t):
@@ -156,17 +161,18 @@ class UserRowExchange:
             from . import _ffi
             raise _ffi.BprxError(rc, what + " failed")
 
-    def plan_native(self, ids):
-        """ids: int32 device tensor [n] of global row ids.  Returns recv_idx [world*cap]: the rows the other ranks ask this rank
-        for (-1 = unused slot); the slots of this rank's own requests stay in the exchange (fetch_native / give_back_native).
-        Rows this rank owns itself are served from / added to its own tables (no trip through the send buffers); with one rank
-        nothing is routed and no collective runs."""
+    def plan_native(self, ids, ids_b=None):
+        """ids (, ids_b): int32 device tensors of global row ids, taken back to back (a batch's positives and negatives need no
+        concatenation).  Returns recv_idx [world*cap]: the rows the other ranks ask this rank for (-1 = unused slot); the slots of
+        this rank's own requests stay in the exchange (fetch_native / give_back_native).  Rows this rank owns itself are served
+        from / added to its own tables (no trip through the send buffers); with one rank nothing is routed and no collective runs.
+        (The send list and the cursors were returned to "empty" by the previous step's give_back_native.)"""
         nat, W = self._nat, self.world
-        n = ids.numel()
-        self._rc(nat["lib"].bprx_route_reset(self._p(nat["send_idx"]), W * nat["cap"], self._p(nat["cursor"]), W, self._s()), "route_reset")
-        self._rc(nat["lib"].bprx_route_plan(self._p(ids), n, self.ush, W, nat["cap"], self.rank, self._p(nat["slot"]),
-                                            self._p(nat["send_idx"]), self._p(nat["cursor"]), self._p(nat["overflow"]), self._s()), "route_plan")
-        nat["n"] = n
+        n, nb = ids.numel(), (ids_b.numel() if ids_b is not None else 0)
+        self._rc(nat["lib"].bprx_route_plan(self._p(ids) if n else None, n, self._p(ids_b) if nb else None, nb, self.ush, W, nat["cap"],
+                                            self.rank, self._p(nat["slot"]), self._p(nat["send_idx"]), self._p(nat["cursor"]),
+                                            self._p(nat["overflow"]), self._p(nat["own_cnt"]), self._s()), "route_plan")
+        nat["n"] = n + nb
         return self._a2a_equal(nat["send_idx"]) if W > 1 else nat["send_idx"]
 
     def fetch_native(self, t0, t1, recv_idx, dst0, dst1):
@@ -177,7 +183,7 @@ class UserRowExchange:
         got = nat["rows_out"]
         if self.world > 1:
             self._rc(nat["lib"].bprx_route_gather(self._p(t0), w0, self._p(t1), w1, t0.shape[0], self._p(recv_idx), recv_idx.numel(),
-                                                  self._p(nat["rows_out"]), self._s()), "route_gather")
+                                                  self._p(nat["rows_out"]), self._p(nat["cnt"]), self._s()), "route_gather")
             got = self._a2a_equal(nat["rows_out"])
         self._rc(nat["lib"].bprx_route_unpack(self._p(got), self._p(nat["slot"]), nat["n"], self._p(dst0), w0, self._p(dst1), w1,
                                               self._p(t0), self._p(t1), t0.shape[0], self._s()), "route_unpack")
@@ -187,12 +193,14 @@ class UserRowExchange:
         their tables."""
         nat = self._nat
         w0, w1 = g0.shape[1], (g1.shape[1] if g1 is not None else 0)
+        W = self.world
         self._rc(nat["lib"].bprx_route_pack(self._p(g0), w0, self._p(g1), w1, self._p(nat["slot"]), nat["n"], self._p(nat["grad_out"]),
-                                            self._p(t0), self._p(t1), t0.shape[0], float(scale), self._s()), "route_pack")
-        if self.world > 1:
+                                            self._p(t0), self._p(t1), t0.shape[0], float(scale), self._p(nat["own_cnt"]),
+                                            self._p(nat["send_idx"]), W * nat["cap"], self._p(nat["cursor"]), W, self._s()), "route_pack")
+        if W > 1:
             back = self._a2a_equal(nat["grad_out"])
             self._rc(nat["lib"].bprx_route_scatter_add(self._p(t0), w0, self._p(t1), w1, t0.shape[0], self._p(recv_idx), self._p(back),
-                                                       recv_idx.numel(), float(scale), self._s()), "route_scatter_add")
+                                                       recv_idx.numel(), float(scale), self._p(nat["cnt"]), self._s()), "route_scatter_add")
 
 
     def fetch_fixed(self, shard_tables, recv_idx, slot, valid):
@@ -511,7 +519,6 @@ class UserShardedBPRMF:
         self.native = bool(fixed_cap)                            # routing in HIP kernels (bprx_route_*)
         if self.native:
             self.x.native_setup(dev, self.cap, 2 * max_batch, k + 1)
-            self.items = torch.empty(2 * max_batch, dtype=torch.int32, device=dev)
 
     @property
     def Bi_shard(self):
@@ -524,10 +531,7 @@ class UserShardedBPRMF:
         if self.fixed_cap and self.native:
             # a routed row is [Gi row | Bi] (k + 1 floats, padded to k + 4): the gather / unpack / pack / scatter-add kernels
             # take the two tables as they are (w0 = k, w1 = 1)
-            items = self.items[:2 * B]
-            items[:B].copy_(i_global)
-            items[B:].copy_(j_global)
-            ridx = self.x.plan_native(items)
+            ridx = self.x.plan_native(i_global, j_global)        # (requests 0..B-1: the positives, B..2B-1: the negatives)
             self.x.fetch_native(self.Gi_shard, self.Bi_col, ridx, self.stage_Gi, self.stage_Bi)
             loss = None
             if B or self.adam:                                   # (adam: an empty batch is still a step -- every row moves)

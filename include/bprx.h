@@ -226,21 +226,32 @@ BPRX_API int bprx_scatter_add(float *table, int32_t num_rows, int32_t num_cols, 
                 bprx_route_pack(grad0, w0, grad1, w1, slot, n, send): send[slot[r]] = [grad0[r] | grad1[r]]; the gradient rows are
                   returned to zero (replaces bprx_clear_*_grad); all-to-all(send) -> back, aligned with recv_idx
      owner      bprx_route_scatter_add(t0, w0, t1, w1, num_rows, recv_idx, back, nranks*cap, scale): t[idx] += scale * row
-                  (fp32 atomics, duplicates summed; unused slots skipped).
+                  (duplicates summed; unused slots skipped).
    Rows the requesting rank owns itself (my_rank; -1: none) never enter the send buffers: bprx_route_plan gives them slot
    -2 - local row id, bprx_route_unpack copies them from own0 / own1 (the rank's shard tables, own_rows rows) and bprx_route_pack
-   adds scale * gradient into own0 / own1 directly. */
+   adds scale * gradient into own0 / own1 directly.
+   bprx_route_plan takes the ids as two arrays back to back (ids[n], then ids_b[n_b]; either may be empty): a triplet batch's
+   positives and negatives need no concatenation.
+   Row multiplicities (own_cnt / cnt: optional, int32 [rows_per_rank] each, all-zero at the start; NULL = every row is added with
+   fp32 atomics): plan counts the requester's own rows into own_cnt, gather counts the rows the other ranks ask for into cnt; pack
+   (own rows) and scatter_add (returned rows) then add a row that occurs ONCE with plain 16-byte read-modify-writes and leave the
+   counts all-zero again by themselves (see bprx_route.hip).  Pass the same array to the pair (plan, pack) and another one to the
+   pair (gather, scatter_add).
+   bprx_route_pack with send_idx != NULL also returns send_idx (nslots entries) to -1 and the nranks cursors to 0 for the next
+   step's plan: bprx_route_reset is then needed once, before the first step. */
 BPRX_API int bprx_route_reset(int32_t *send_idx, int64_t nslots, int32_t *cursor, int32_t nranks, void *stream);
-BPRX_API int bprx_route_plan(const int32_t *ids, int64_t n, int32_t rows_per_rank, int32_t nranks, int32_t cap, int32_t my_rank,
-                             int32_t *slot, int32_t *send_idx, int32_t *cursor, int32_t *overflow, void *stream);
+BPRX_API int bprx_route_plan(const int32_t *ids, int64_t n, const int32_t *ids_b, int64_t n_b, int32_t rows_per_rank, int32_t nranks,
+                             int32_t cap, int32_t my_rank, int32_t *slot, int32_t *send_idx, int32_t *cursor, int32_t *overflow,
+                             int32_t *own_cnt, void *stream);
 BPRX_API int bprx_route_gather(const float *t0, int32_t w0, const float *t1, int32_t w1, int32_t num_rows, const int32_t *idx,
-                               int64_t n, float *out, void *stream);
+                               int64_t n, float *out, int32_t *cnt, void *stream);
 BPRX_API int bprx_route_unpack(const float *got, const int32_t *slot, int64_t n, float *dst0, int32_t w0, float *dst1, int32_t w1,
                                const float *own0, const float *own1, int32_t own_rows, void *stream);
 BPRX_API int bprx_route_pack(float *src0, int32_t w0, float *src1, int32_t w1, const int32_t *slot, int64_t n, float *send,
-                             float *own0, float *own1, int32_t own_rows, float scale, void *stream);
+                             float *own0, float *own1, int32_t own_rows, float scale, int32_t *own_cnt, int32_t *send_idx,
+                             int64_t nslots, int32_t *cursor, int32_t nranks, void *stream);
 BPRX_API int bprx_route_scatter_add(float *t0, int32_t w0, float *t1, int32_t w1, int32_t num_rows, const int32_t *idx,
-                                    const float *rows, int64_t n, float scale, void *stream);
+                                    const float *rows, int64_t n, float scale, int32_t *cnt, void *stream);
 
 /* Model.predict_all() rows [u0,u1)   BPRMF.py:78-85 / VBPR.py:88-97.   out: fp32 [(u1-u0), I] */
 BPRX_API int bprx_score_block(bprx_handle *h, int32_t u0, int32_t u1, float *out, void *stream);
