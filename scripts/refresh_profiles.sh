@@ -12,8 +12,9 @@ echo "== rocprof kernel stats"; t 400 rocprofv3 --kernel-trace --stats --output-
 find $O/prof -name "c2_kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $O/bench_c2_kernel_stats.csv
 t 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof5 -o c5 -- python bench.py --workload c5 --steps 30 --repeats 2 --min-timed-seconds 0 --no-cpu-baseline > $O/prof5.log 2>&1
 find $O/prof5 -name "c5_kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $O/bench_c5_kernel_stats.csv
-echo "== pmc (c2)"; t 600 scripts/pmc.sh > $O/pmc_run.log 2>&1; cp gpurun_out/pmc_summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json
-echo "== pmc (c5)"; BENCH_ARGS="--workload c5" t 600 scripts/pmc.sh > $O/pmc5_run.log 2>&1; cp gpurun_out/pmc_summary.txt $O/pmc_c5_summary.txt; cp gpurun_out/pmc_traffic.json $O/pmc_c5_traffic.json
+rm -rf $O/prof $O/prof5
+echo "== pmc (c2)"; t 600 scripts/pmc.sh > $O/pmc_run.log 2>&1; cp gpurun_out/pmc_summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json; rm -rf gpurun_out/pmc_sq gpurun_out/pmc_mfma gpurun_out/pmc_fetch gpurun_out/pmc_write
+echo "== pmc (c5)"; BENCH_ARGS="--workload c5" t 600 scripts/pmc.sh > $O/pmc5_run.log 2>&1; cp gpurun_out/pmc_summary.txt $O/pmc_c5_summary.txt; cp gpurun_out/pmc_traffic.json $O/pmc_c5_traffic.json; rm -rf gpurun_out/pmc_sq gpurun_out/pmc_mfma gpurun_out/pmc_fetch gpurun_out/pmc_write   # (raw counter CSVs: > 64 MiB, gpurun would not copy anything back)
 echo "== other workloads"
 : > $O/bench_others.jsonl
 IFS='|' read -ra LIST <<< "--workload c3shard|--workload c4shard|--workload c5 --steps 50|--workload c5list --steps 100|--workload c5small|--workload c2fp8|--workload c5bf16|--optimizer adam_tf23|--workload c4shard --optimizer adam_tf23|--workload c3shard --optimizer adam_tf23|--batch 256|--batch 4096|--batch 16384|--sampler philox|--zipf 1.0"
