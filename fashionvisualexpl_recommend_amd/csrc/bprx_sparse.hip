@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
                                                       const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
   constexpr int T = TS_T / G;                               // triplets per workgroup (<= 64)
   __shared__ __attribute__((aligned(16))) float rows[4096];  // [T][k + d], k + d <= 8 G
-  __shared__ int s_user[T], s_slot[T];
+  __shared__ int s_user[T], s_slot[T], s_cnt[T];
   const int tl = threadIdx.x / G, lane = threadIdx.x % G;
   const int64_t b0 = (int64_t)blockIdx.x * T + tl;
   const bool valid = b0 < B;                                // (the surplus groups of the last workgroup run along: barriers)
@@ -1292,8 +1292,8 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
     const unsigned top = (unsigned)a.seg_cap - 1u;          // (never beyond the allocation, whatever the index state holds)
     spI = (int)((unsigned)spI < top ? (unsigned)spI : top); spJ = (int)((unsigned)spJ < top ? (unsigned)spJ : top);
   }
-  int slot = 0;
-  if (su.mode == 0) slot = su.uslot_of[u];
+  int slot = 0, ucnt = 0;
+  if (su.mode == 0) { slot = su.uslot_of[u]; ucnt = a.cntU[u]; }    // (the user's occurrences in the batch: final since k_index_seg)
   const int c4 = lane * 4;
   const bool hk = c4 < k, hd = c4 < d;
   const int ck = hk ? c4 : 0, cd = hd ? c4 : 0;
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
                                                               g * (q.z - r.z) + r2 * p.z, g * (q.w - r.w) + r2 * p.w);
   if (hd) *reinterpret_cast<float4 *>(row + k + c4) = make_float4(g * (tq.x - tr.x) + r2 * tp.x, g * (tq.y - tr.y) + r2 * tp.y,
                                                                   g * (tq.z - tr.z) + r2 * tp.z, g * (tq.w - tr.w) + r2 * tp.w);
-  if (lane == 0) { s_user[tl] = valid ? u : -1 - tl; s_slot[tl] = slot; }
+  if (lane == 0) { s_user[tl] = valid ? u : -1 - tl; s_slot[tl] = slot; s_cnt[tl] = ucnt; }
   __syncthreads();
   const int wl = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int myu = wl < T ? s_user[wl] : 0, pru = (wl > 0 && wl < T) ? s_user[wl - 1] : 0;
@@ -1378,13 +1378,30 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
     // mode 0: the run's sum meets the user's other runs in the staging row (fire and forget: the totals are applied by the
     // finishing lane groups of k_item_seg, after this kernel); the segment that starts at the user's slot -- the first run
     // head of the user in the batch -- saves the PRE-update row for k_item_seg's gathers
-#pragma unroll
-    for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) atomicAdd(c < k ? sG + c : sT + (c - k), acc[x]); }
+    // A user whose ONLY run this is (its occurrence count equals the run's length: most users of a batch in the reference's
+    // visiting order, every user of an i.i.d. batch) takes its update right here -- no staging round trip, nothing left for
+    // the finishing groups (count back to zero = "done").  Every triplet of the run has read the row before the barrier above,
+    // and no other workgroup holds a triplet of this user.  Same arithmetic as the finishing pass: row - lr * (0 + sum).
     const int sl = s_slot[s0];
-    if ((int64_t)blockIdx.x * T + s0 == (int64_t)sl) {
+    const bool head = (int64_t)blockIdx.x * T + s0 == (int64_t)sl;
+    const bool excl = head && s_cnt[s0] == s1 - s0;
+    if (!excl) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) atomicAdd(c < k ? sG + c : sT + (c - k), acc[x]); }
+    }
+    if (head) {
       float *const uo = su.uold + (size_t)sl * kd;
 #pragma unroll
-      for (int x = 0; x < 8; ++x) { const int c = wl + 64 * x; if (c < kd) uo[c] = c < k ? tG[c] : tT[c - k]; }
+      for (int x = 0; x < 8; ++x) {
+        const int c = wl + 64 * x;
+        if (c < kd) {
+          float *const tp = c < k ? tG + c : tT + (c - k);
+          const float old = *tp;
+          uo[c] = old;
+          if (excl) *tp = old - a.lr * acc[x];
+        }
+      }
+      if (excl && wl == 0) a.cntU[uu] = 0;
     }
   }
 }
@@ -1424,6 +1441,7 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
     const int c4 = lane * 4;
     for (int e = ((int)blockIdx.x * 256 + (int)threadIdx.x) / G; e < n; e += ngroups) {
       const int u = clamp_quiet(a.ulist[e], a.U);
+      if (a.cntU[u] == 0) continue;                      // a user of one run: k_triplet_seg has finished it (group-uniform)
       if (c4 < a.k) {
         float *t = a.wGu + (size_t)u * a.k + c4, *g = a.dGu + (size_t)u * a.k + c4;
         const float4 tv = ld4(t), gv = ld4(g);
