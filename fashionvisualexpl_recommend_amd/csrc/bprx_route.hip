@@ -24,7 +24,9 @@
 // back to zero; more -> float atomics as before, then one returning add of 0x10000: the occurrence that finds every other one
 // finished (high half + 1 == low half) returns the count to zero.  A reader can never mistake a partly finished row for an
 // exclusive one (its count is never exactly 1), so no pass is needed to clear the counts.  Own and returned rows are added by
-// different (stream-ordered) kernels, hence two count arrays.
+// different (stream-ordered) kernels, hence two count arrays.  (A row asked for more than 65 535 times in one step overflows the
+// halves: its count may then never return to zero and the row keeps the atomic path -- slower, never wrong: a count equals 1
+// only for a clean row with one occurrence.)
 #include "bprx_internal.h"
 
 namespace {
