@@ -136,10 +136,11 @@ static void plane_args(bprx_handle *h, const int32_t *pos, const int32_t *neg, i
                        uint8_t **own8, uint8_t **loc8, long long *pl_i, long long *pl_j) {
   *own8 = nullptr; *loc8 = nullptr; *pl_i = 0; *pl_j = 0;
   if (!h || !h->own8 || batch_size <= 0 || batch_size > h->cfg.max_batch || batch_offset < 0 || batch_offset + B > batch_size) return;
-  const int32_t *pos0 = pos - batch_offset, *neg0 = neg - batch_offset;
-  if (batch_offset == 0) { h->idx8_pos = pos0; h->idx8_neg = neg0; h->idx8_B = batch_size; h->idx8_n = 0; }
-  else if (h->idx8_pos != pos0 || h->idx8_neg != neg0 || h->idx8_B != batch_size) { h->idx8_n = -1; return; }
-  if (h->idx8_n < 0) return;
+  if (batch_offset == 0) { h->idx8_pos = pos; h->idx8_neg = neg; h->idx8_B = batch_size; h->idx8_n = 0; }
+  else if (h->idx8_n < 0 || h->idx8_B != batch_size || pos != h->idx8_pos + batch_offset || neg != h->idx8_neg + batch_offset) {
+    h->idx8_n = -1;                                        // not a continuation of the batch begun at offset 0: no planes
+    return;
+  }
   h->idx8_n += B;
   *own8 = h->own8; *loc8 = h->loc8; *pl_i = batch_offset; *pl_j = batch_size + batch_offset;
 }
