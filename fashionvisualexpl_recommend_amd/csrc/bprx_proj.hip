@@ -1224,15 +1224,12 @@ void launch_v10(bprx_handle *h, int64_t nrows, float *Pout, hipStream_t s, int n
   if (nw < NWMIN) nw = NWMIN;
   const size_t lds = (size_t)2 * NT * 16 * 288 + (size_t)nw * 2 * 16 * 288;
   const bool ntl = fwd_nt_loads(h);
-  // every workgroup starts at another 128-column chunk (chunk order rotated by the workgroup index): the [E|Bp]^T chunks are
-  // not all asked of the L2s at the same moment (same-box A/B: c4shard forward 117.4 -> 113.0 us, C2 neutral)
-  const int xstag = 1;
 #define V10_LAUNCH(F8_, NTL_)                                                                                             \
   do {                                                                                                                    \
     auto kfn = k_proj_fwd_bf16_v10<NT, F8_, NTL_>;                                                                        \
     (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(nw * 64), lds, s, (const uint16_t *)h->Ft, (int)nrows, Deq,            \
-                       (const uint16_t *)h->Et, Pout, h->PS, pscale, xstag, per_wave, n0);                                     \
+                       (const uint16_t *)h->Et, Pout, h->PS, pscale, 0, per_wave, n0);                                     \
   } while (0)
   if (f8) { if (ntl) V10_LAUNCH(true, true); else V10_LAUNCH(true, false); }
   else { if (ntl) V10_LAUNCH(false, true); else V10_LAUNCH(false, false); }
