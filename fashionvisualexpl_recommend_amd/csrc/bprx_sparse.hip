@@ -1263,7 +1263,8 @@ __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
 // In the reference's visiting order (runs of ~20 triplets) that is 2 atomic row adds per workgroup of 32 triplets instead of
 // one per wave or per triplet, and every sum inside a run is taken in batch order.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TS_T = 512;
+constexpr int TS_T = 256;    // (same-box A/B of 128 / 256 / 512 threads: 256 wins on every shape -- C2 30.1 -> 25.7 us, c5 390 -> 348,
+                             //  c4shard 51 -> 43.5, i.i.d. batches 54.9 -> 48.3; 512 was round 3's first choice, 128 loses to both)
 
 struct SegUser {
   int mode;
