@@ -1429,8 +1429,10 @@ __global__ __launch_bounds__(TS_T) void k_triplet_seg(SparseArgs a, SegUser su, 
 //           gradient (the row is current: k_adam_catchup ran) -- no staging round trip, no apply pass for the items.
 struct AdamFuse { float *mGi, *vGi, *mBi, *vBi; int32_t *lastI; float b1, b2, eps; int t; };
 
+constexpr int IS_T = 256;     // threads of an item-segment workgroup
+
 template <int G, int ADAM>
-__global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
+__global__ __launch_bounds__(IS_T) void k_item_seg(SparseArgs a, float *__restrict__ Gi, float *__restrict__ Bi,
                                                   float *__restrict__ Wf, uint16_t *__restrict__ Wb, float lr, AdamFuse af) {
   const int lane = threadIdx.x % G;
   if ((int)blockIdx.x < a.nfin) {
@@ -1438,9 +1440,9 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
     // rows, take their update here: table row -= lr * total, staging row and occurrence count back to zero.  (The item groups
     // of this launch gather the PRE-update user rows from uold, not from the tables.)
     const int n = a.ulist_n[0];
-    const int ngroups = a.nfin * (256 / G);
+    const int ngroups = a.nfin * (IS_T / G);
     const int c4 = lane * 4;
-    for (int e = ((int)blockIdx.x * 256 + (int)threadIdx.x) / G; e < n; e += ngroups) {
+    for (int e = ((int)blockIdx.x * IS_T + (int)threadIdx.x) / G; e < n; e += ngroups) {
       const int u = clamp_quiet(a.ulist[e], a.U);
       if (a.cntU[u] == 0) continue;                      // a user of one run: k_triplet_seg has finished it (group-uniform)
       if (c4 < a.k) {
@@ -1529,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_item_seg(SparseArgs a, float *__restric
     // The chunk's partial rows leave in the lane = element layout (through a per-group LDS row): an atomic wave-instruction
     // then covers contiguous dwords -- 4 memory-side requests per row of 64 floats instead of 16 with the float4 layout
     // (each 64-B line hit by four instructions); all chunks of a hot item queue on the same few lines.
-    __shared__ __attribute__((aligned(16))) float s_hot[256 / G][4 * G];
+    __shared__ __attribute__((aligned(16))) float s_hot[IS_T / G][4 * G];
     float *hrow = s_hot[threadIdx.x / G];
     float *const gdst = a.dGi + (size_t)item * k;
     if (hk) *reinterpret_cast<float4 *>(hrow + c4) = gr;
@@ -2160,15 +2162,15 @@ int bprx_launch_item_seg(bprx_handle *h, const int32_t *i, const int32_t *j, int
   const int64_t bound = (int64_t)h->seg_lead_over + 2 * B / SEG_CAP + 64;
   // (the finishing workgroups stride over the batch's users -- a few thousand in the reference's visiting order, up to B for
   //  i.i.d. batches: sized for a quarter of B, the surplus ones leave after one load)
-  int64_t nfin = B * G / 256 / 4;
+  int64_t nfin = B * G / IS_T / 4;
   nfin = nfin < 16 ? 16 : (nfin > 2048 ? 2048 : nfin);
   a.nfin = seg_finishes_users(h) ? (int)nfin : 0;
-  const dim3 grid((unsigned)(grid_for(bound, G).x + a.nfin));
+  const dim3 grid((unsigned)((bound * G + IS_T - 1) / IS_T + a.nfin));
 #define LAUNCH_SEG(GG)                                                                                                   \
   do {                                                                                                                   \
-    if (adam == 2) hipLaunchKernelGGL((k_item_seg<GG, 2>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
-    else if (adam) hipLaunchKernelGGL((k_item_seg<GG, 1>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
-    else hipLaunchKernelGGL((k_item_seg<GG, 0>), grid, dim3(256), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af);          \
+    if (adam == 2) hipLaunchKernelGGL((k_item_seg<GG, 2>), grid, dim3(IS_T), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
+    else if (adam) hipLaunchKernelGGL((k_item_seg<GG, 1>), grid, dim3(IS_T), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af); \
+    else hipLaunchKernelGGL((k_item_seg<GG, 0>), grid, dim3(IS_T), 0, s, a, h->t.Gi, h->t.Bi, Wf, Wb, lr_t, af);          \
   } while (0)
   switch (G) {
     case 8: LAUNCH_SEG(8); break;
