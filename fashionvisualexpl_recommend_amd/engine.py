@@ -4,7 +4,6 @@ PyTorch is plumbing here (device memory, streams); every computation of the hot 
 libbprx.so through the C ABI (include/bprx.h).  A missing library or a missing GPU raises.
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -396,44 +395,24 @@ class EpochWalkSampler(PhiloxSampler):
         driver's form cannot hide a host stall and read 4 % above the 200-step regions; an asynchronous pinned-memory upload
         behind a deep launch queue was worse: intermittent 25-80 ms stalls.)"""
         U = self.indptr.numel() - 1
-        main = torch.cuda.current_stream(self.device)
         if getattr(self, "_iota", None) is None:
             self._iota = torch.arange(U, dtype=torch.int32, device=self.device)
-            self._lens = self.indptr[1:] - self.indptr[:-1]
-            # The dozen small kernels of a preparation (key kernel, radix / merge sort passes, gather, two scans, fill: ~120 us
-            # of GPU time, more when the host is not ahead) run on a stream of their own: the result is needed an epoch later,
-            # so they fill whatever the step kernels leave free instead of standing in front of the next step (C2: one
-            # preparation per 30 steps = 4 us per step in 200-step timed regions, 8 in 20-step ones, before this).
-            self._prep_stream = torch.cuda.Stream(device=self.device) if os.environ.get("BPRX_EPOCH_PREP_STREAM", "1") != "0" else None
-            if self._prep_stream is not None:
-                self._prep_stream.wait_stream(main)              # (indptr / _iota / _lens were produced on the caller's stream)
-        side = self._prep_stream
-        with torch.cuda.stream(side if side is not None else main):
-            keys = torch.empty(U, dtype=torch.int64, device=self.device)
-            rc = self.lib.bprx_epoch_keys(self.seed, epoch, U, _ptr(keys), _stream())
-            if rc < 0:
-                raise _ffi.BprxError(rc, "bprx_epoch_keys failed")
-            perm_d = torch.sort(keys, stable=True).indices.to(torch.int32)
-            lens = self._lens.index_select(0, perm_d.long())
-            epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
-            torch.cumsum(lens, 0, out=epoch_ptr[1:])
-            # position -> slot of its user in the epoch order, once per epoch (4 B per interaction): saves the per-triplet
-            # binary search over epoch_ptr in the kernel
-            pos_slot = torch.repeat_interleave(self._iota, lens, output_size=self.num_pos)
-            ready = None
-            if side is not None:
-                ready = torch.cuda.Event()
-                ready.record(side)
-        return dict(epoch=epoch, perm=perm_d, epoch_ptr=epoch_ptr, pos_slot=pos_slot, ready=ready)
+        keys = torch.empty(U, dtype=torch.int64, device=self.device)
+        rc = self.lib.bprx_epoch_keys(self.seed, epoch, U, _ptr(keys), _stream())
+        if rc < 0:
+            raise _ffi.BprxError(rc, "bprx_epoch_keys failed")
+        perm_d = torch.sort(keys, stable=True).indices.to(torch.int32)
+        lens = (self.indptr[1:] - self.indptr[:-1]).index_select(0, perm_d.long())
+        epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens, 0, out=epoch_ptr[1:])
+        # position -> slot of its user in the epoch order, once per epoch (4 B per interaction): saves the per-triplet
+        # binary search over epoch_ptr in the kernel
+        pos_slot = torch.repeat_interleave(self._iota, lens, output_size=self.num_pos)
+        return dict(epoch=epoch, perm=perm_d, epoch_ptr=epoch_ptr, pos_slot=pos_slot)
 
     def _start_epoch(self, epoch):
         nxt = getattr(self, "_next", None)
         cur = nxt if (nxt is not None and nxt["epoch"] == epoch) else self._prepare(epoch)
-        if cur["ready"] is not None:                             # prepared on the side stream: the sampler kernels wait for it,
-            main = torch.cuda.current_stream(self.device)        # and the allocator must not hand the memory out while they read
-            main.wait_event(cur["ready"])
-            for t in (cur["perm"], cur["epoch_ptr"], cur["pos_slot"]):
-                t.record_stream(main)
         self.perm, self.epoch_ptr, self.pos_slot = cur["perm"], cur["epoch_ptr"], cur["pos_slot"]
         self.epoch, self.pos_in_epoch = epoch, 0
         self._next = self._prepare(epoch + 1)
