@@ -109,7 +109,8 @@ def lib():
         "bprx_pack_user_msg": (C.c_int, [vp, vp, i64, i64, vp, vp]),
         "bprx_apply_user_msgs": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
         "bprx_sum_dense_parts": (C.c_int, [vp, vp, i32, vp]),
-        "bprx_epoch_keys": (C.c_int, [C.c_uint64, u32, i32, vp, vp]),
+        "bprx_epoch_prepare": (C.c_int, [C.c_uint64, u32, i32, vp, vp, vp, vp]),
+        "bprx_epoch_slots": (C.c_int, [vp, i32, vp, vp]),
         "bprx_sample_epoch": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_uint64, u32, i64, i64, vp, vp, vp, vp]),
         "bprx_index_pass_kind": (C.c_int, [vp]),
         "bprx_adam_rows": (C.c_int, [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
@@ -136,7 +137,7 @@ EXPORTS = ["bprx_abi_version", "bprx_create", "bprx_destroy", "bprx_last_error",
            "bprx_dense_grad", "bprx_step_end", "bprx_step_project", "bprx_user_grad", "bprx_clear_user_grad", "bprx_item_grad", "bprx_clear_item_grad",
            "bprx_scatter_add", "bprx_route_reset", "bprx_route_plan", "bprx_route_gather", "bprx_route_unpack", "bprx_route_pack",
            "bprx_route_scatter_add", "bprx_score_block", "bprx_eval_users", "bprx_eval_pos", "bprx_eval_counts", "bprx_eval_finish", "bprx_topk", "bprx_sync_check", "bprx_probe_stream_read", "bprx_probe_stream_read_nt", "bprx_probe_row_gather", "bprx_profile_enable",
-           "bprx_profile_read", "bprx_sample_philox", "bprx_epoch_keys", "bprx_sample_epoch", "bprx_sample_philox_h", "bprx_sample_epoch_h", "bprx_index_pass_kind", "bprx_adam_rows", "bprx_step_lr", "bprx_user_msg_floats", "bprx_pack_user_msg",
+           "bprx_profile_read", "bprx_sample_philox", "bprx_epoch_prepare", "bprx_epoch_slots", "bprx_sample_epoch", "bprx_sample_philox_h", "bprx_sample_epoch_h", "bprx_index_pass_kind", "bprx_adam_rows", "bprx_step_lr", "bprx_user_msg_floats", "bprx_pack_user_msg",
            "bprx_apply_user_msgs", "bprx_sampler_create",
            "bprx_sampler_destroy", "bprx_sampler_count", "bprx_sampler_ref_stream"]
 

@@ -106,23 +106,69 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
   }
 }
 
-// Sort keys of an epoch's user order: key[u] = 63 bits of philox(key = seed, ctr = (u, 0, 0xFFFFFFFF, epoch)) -- the third
-// counter word never collides with the negative draws (attempt numbers < 1024).  The epoch's order is the STABLE ascending
-// argsort of the keys (caller: a device radix sort); the CPU twin computes the same keys (oracle orc_epoch_keys).
-__global__ __launch_bounds__(256) void k_epoch_keys(uint32_t k0, uint32_t k1, uint32_t epoch, int U, int64_t *__restrict__ keys) {
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= U) return;
-  uint32_t r[4];
-  philox4x32_10((uint32_t)u, 0u, 0xFFFFFFFFu, epoch, k0, k1, r);
-  keys[u] = (int64_t)((((unsigned long long)(r[1] & 0x7fffffffu)) << 32) | r[0]);
+// The user order of an epoch: a keyed permutation of [0, U) evaluated POINTWISE -- slot a of epoch `epoch` holds user
+//   perm(a) = cycle-walk of a 4-round Feistel network over 2*half bits (half = ceil(bits(U-1) / 2)), round function
+//             F_r(R) = philox(key = seed, ctr = (R, r, 0xFFFFFFFE, epoch))[0] & (2^half - 1); walk until the value is < U
+// (a bijection of [0, 2^(2 half)) restricted to [0, U) by cycle-walking: a bijection of [0, U); < 4 walks on average).  No keys,
+// no sort: until the end of round 3 the order was the stable argsort of per-user Philox keys -- a device merge sort of 8 launches
+// and 60 us per epoch inside a preparation of 23 launches and 158 us (5 us per C2 step); this is one launch of a few us.  The third
+// counter word never collides with the negative draws (attempt numbers < 1024).  CPU twin: oracle orc_epoch_perm.
+__device__ __forceinline__ uint32_t epoch_perm_at(uint32_t a, uint32_t U, int half, uint32_t k0, uint32_t k1, uint32_t epoch) {
+  const uint32_t mask = (1u << half) - 1u;
+  uint32_t x = a;
+  do {
+    uint32_t L = x >> half, R = x & mask;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+      uint32_t o[4];
+      philox4x32_10(R, r, 0xFFFFFFFEu, epoch, k0, k1, o);
+      const uint32_t t = L ^ (o[0] & mask);
+      L = R; R = t;
+    }
+    x = (L << half) | R;
+  } while (x >= U);
+  return x;
+}
+
+__host__ __device__ inline int epoch_perm_half(uint32_t U) {          // half the bits of the Feistel domain (>= 1)
+  int nb = 1;
+  while (nb < 32 && (U - 1u) >> nb) ++nb;
+  return (nb + 1) / 2;
+}
+
+// slot a -> its user and the length of that user's list (the prefix sums of the lengths are the epoch's position offsets)
+__global__ __launch_bounds__(256) void k_epoch_prepare(uint32_t k0, uint32_t k1, uint32_t epoch, int U, int half,
+                                                       const int64_t *__restrict__ indptr, int32_t *__restrict__ perm,
+                                                       int64_t *__restrict__ lens) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= U) return;
+  const uint32_t u = epoch_perm_at((uint32_t)a, (uint32_t)U, half, k0, k1, epoch);
+  perm[a] = (int32_t)u;
+  lens[a] = indptr[u + 1] - indptr[u];
+}
+
+// position -> slot: positions [epoch_ptr[a], epoch_ptr[a+1]) belong to slot a (one lane group of 8 per slot)
+__global__ __launch_bounds__(256) void k_epoch_slots(const int64_t *__restrict__ epoch_ptr, int U, int32_t *__restrict__ pos_slot) {
+  const int a = (blockIdx.x * 256 + threadIdx.x) >> 3, lane = threadIdx.x & 7;
+  if (a >= U) return;
+  const int64_t p0 = epoch_ptr[a], p1 = epoch_ptr[a + 1];
+  for (int64_t p = p0 + lane; p < p1; p += 8) pos_slot[p] = a;
 }
 
 }  // namespace
 
-extern "C" int bprx_epoch_keys(uint64_t seed, uint32_t epoch, int32_t num_users, int64_t *keys, void *stream) {
-  if (!keys || num_users <= 0) return BPRX_E_INVALID;
-  hipLaunchKernelGGL(k_epoch_keys, dim3((unsigned)((num_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), epoch, num_users, keys);
+extern "C" int bprx_epoch_prepare(uint64_t seed, uint32_t epoch, int32_t num_users, const int64_t *indptr, int32_t *perm,
+                                  int64_t *lens, void *stream) {
+  if (!indptr || !perm || !lens || num_users <= 0) return BPRX_E_INVALID;
+  hipLaunchKernelGGL(k_epoch_prepare, dim3((unsigned)((num_users + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), epoch, num_users, epoch_perm_half((uint32_t)num_users), indptr, perm, lens);
+  return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
+}
+
+extern "C" int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int32_t *pos_slot, void *stream) {
+  if (!epoch_ptr || !pos_slot || num_users <= 0) return BPRX_E_INVALID;
+  hipLaunchKernelGGL(k_epoch_slots, dim3((unsigned)(((int64_t)num_users * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     epoch_ptr, num_users, pos_slot);
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 

@@ -383,31 +383,32 @@ class PhiloxSampler:
 
 class EpochWalkSampler(PhiloxSampler):
     """bprx_sample_epoch: the reference's visiting order as a device stream -- per epoch a fresh permutation of the users
-    (the stable argsort of per-user Philox keys, computed on the device), every positive of every user exactly once,
+    (a keyed Feistel permutation evaluated on the device, bprx_epoch_prepare), every positive of every user exactly once,
     consecutively; negatives by Philox rejection.  Batches are user-grouped like the reference's."""
 
     def _prepare(self, epoch):
-        """Everything epoch `epoch` needs, ENQUEUED without a host synchronisation or an upload: the user order is the stable
-        argsort of per-user Philox keys (bprx_epoch_keys + a device radix sort; the CPU twin sorts the same keys), the prefix sums
-        of the list lengths in that order and the position -> slot map are device ops (repeat_interleave with a known output
-        size).  Prepared ONE EPOCH AHEAD, so that an epoch switch inside a training loop is a pointer swap.  (Until round 3 the
-        permutation was drawn on the host and copied synchronously at every epoch start: bench.py's 20-step timed regions of the
-        driver's form cannot hide a host stall and read 4 % above the 200-step regions; an asynchronous pinned-memory upload
-        behind a deep launch queue was worse: intermittent 25-80 ms stalls.)"""
+        """Everything epoch `epoch` needs, ENQUEUED without a host synchronisation or an upload: the user order is a keyed Feistel
+        permutation evaluated pointwise on the device (bprx_epoch_prepare: slot -> user and the length of its list; CPU twin: the
+        oracle's orc_epoch_perm), the prefix sums of the lengths are one device scan, the position -> slot map one more launch
+        (bprx_epoch_slots).  Prepared ONE EPOCH AHEAD, so that an epoch switch inside a training loop is a pointer swap.
+        (History: until round 3 the permutation was drawn on the host and copied synchronously at every epoch start -- bench.py's
+        20-step timed regions cannot hide a host stall; an asynchronous pinned-memory upload behind a deep launch queue was worse:
+        intermittent 25-80 ms stalls; then the stable argsort of per-user Philox keys on the device: exact, but a merge sort of 8
+        launches inside a preparation of 23 launches and 158 us per epoch = 5 us per C2 step.)"""
         U = self.indptr.numel() - 1
-        if getattr(self, "_iota", None) is None:
-            self._iota = torch.arange(U, dtype=torch.int32, device=self.device)
-        keys = torch.empty(U, dtype=torch.int64, device=self.device)
-        rc = self.lib.bprx_epoch_keys(self.seed, epoch, U, _ptr(keys), _stream())
+        perm_d = torch.empty(U, dtype=torch.int32, device=self.device)
+        lens = torch.empty(U, dtype=torch.int64, device=self.device)
+        rc = self.lib.bprx_epoch_prepare(self.seed, epoch, U, _ptr(self.indptr), _ptr(perm_d), _ptr(lens), _stream())
         if rc < 0:
-            raise _ffi.BprxError(rc, "bprx_epoch_keys failed")
-        perm_d = torch.sort(keys, stable=True).indices.to(torch.int32)
-        lens = (self.indptr[1:] - self.indptr[:-1]).index_select(0, perm_d.long())
+            raise _ffi.BprxError(rc, "bprx_epoch_prepare failed")
         epoch_ptr = torch.zeros(U + 1, dtype=torch.int64, device=self.device)
         torch.cumsum(lens, 0, out=epoch_ptr[1:])
         # position -> slot of its user in the epoch order, once per epoch (4 B per interaction): saves the per-triplet
         # binary search over epoch_ptr in the kernel
-        pos_slot = torch.repeat_interleave(self._iota, lens, output_size=self.num_pos)
+        pos_slot = torch.empty(self.num_pos, dtype=torch.int32, device=self.device)
+        rc = self.lib.bprx_epoch_slots(_ptr(epoch_ptr), U, _ptr(pos_slot), _stream())
+        if rc < 0:
+            raise _ffi.BprxError(rc, "bprx_epoch_slots failed")
         return dict(epoch=epoch, perm=perm_d, epoch_ptr=epoch_ptr, pos_slot=pos_slot)
 
     def _start_epoch(self, epoch):

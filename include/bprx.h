@@ -344,17 +344,23 @@ BPRX_API int bprx_sample_philox(const int64_t *indptr, const int32_t *items_sort
                                 int32_t *user, int32_t *pos, int32_t *neg, void *stream);
 
 /* Epoch-walk mode of the device sampler (the reference's visiting order, dataset.py:93-107, as a stateless stream):
-   in epoch `epoch` users come in the order perm[0..U) (see bprx_epoch_keys) and every positive of a user is emitted once, consecutively;
+   in epoch `epoch` users come in the order perm[0..U) (see bprx_epoch_prepare) and every positive of a user is emitted once, consecutively;
    position n = first + b of the epoch belongs to the user a with epoch_ptr[a] <= n < epoch_ptr[a+1], epoch_ptr being the
    exclusive prefix sums of the list lengths in perm order (int64 [U+1], epoch_ptr[U] = number of interactions).
    pos_slot (optional, int32 [epoch_ptr[U]]): pos_slot[n] = that a, precomputed once per epoch; NULL = binary search per
    triplet (17 dependent loads at U = 100 000: 11.6 vs 6 us per batch of 65 536).
    The caller must keep first + B <= epoch_ptr[U] (a batch that crosses an epoch boundary is two calls).  Negatives as in
    bprx_sample_philox, keyed by (seed; n, epoch).  All pointers are DEVICE pointers. */
-/* The user order of epoch `epoch`: keys int64 [num_users] (device), key[u] = 63 bits of Philox(seed; u, epoch); the epoch visits
-   the users in the STABLE ascending order of their keys (the caller sorts on the device: no host permutation, no upload --
-   an epoch switch never waits for the host).  CPU twin: the oracle's orc_epoch_keys. */
-BPRX_API int bprx_epoch_keys(uint64_t seed, uint32_t epoch, int32_t num_users, int64_t *keys, void *stream);
+/* The user order of epoch `epoch`, prepared on the device without a sort and without the host:
+     bprx_epoch_prepare  perm[a] (int32 [num_users]) = the user in slot a: a keyed permutation evaluated pointwise (4-round Feistel
+                         network over 2*ceil(bits(U-1)/2) bits with Philox round functions keyed by (seed, epoch), cycle-walked
+                         into [0, U); CPU twin: the oracle's orc_epoch_perm), and lens[a] (int64 [num_users]) = the length of
+                         that user's list; the caller's inclusive prefix sums of lens behind a leading 0 are epoch_ptr;
+     bprx_epoch_slots    pos_slot[p] = a for the positions p in [epoch_ptr[a], epoch_ptr[a+1]).
+   Three launches and one scan per epoch; an epoch switch never waits for the host. */
+BPRX_API int bprx_epoch_prepare(uint64_t seed, uint32_t epoch, int32_t num_users, const int64_t *indptr, int32_t *perm,
+                                int64_t *lens, void *stream);
+BPRX_API int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int32_t *pos_slot, void *stream);
 BPRX_API int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
                                const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items, uint64_t seed,
                                uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,

@@ -564,12 +564,27 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* sort keys of an epoch's user order (twin of k_epoch_keys): 63 bits of philox(key = seed, ctr = (u, 0, 0xFFFFFFFF, epoch)) */
-void orc_epoch_keys(uint64_t seed, uint32_t epoch, int32_t U, int64_t *keys) {
-  for (int32_t u = 0; u < U; u++) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)u, 0, 0xFFFFFFFFu, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    keys[u] = (int64_t)((((uint64_t)(r[1] & 0x7fffffffu)) << 32) | r[0]);
+/* the user order of an epoch (twin of k_epoch_prepare / epoch_perm_at in bprx_philox.hip): a 4-round Feistel network over
+   2*half bits, half = ceil(bits(U-1)/2), round function philox(key = seed, ctr = (R, r, 0xFFFFFFFE, epoch))[0] & mask,
+   cycle-walked into [0, U) */
+void orc_epoch_perm(uint64_t seed, uint32_t epoch, int32_t U, int32_t *perm) {
+  int nb = 1;
+  while (nb < 32 && ((uint32_t)U - 1u) >> nb) nb++;
+  const int half = (nb + 1) / 2;
+  const uint32_t mask = (1u << half) - 1u;
+  for (int32_t a = 0; a < U; a++) {
+    uint32_t x = (uint32_t)a;
+    do {
+      uint32_t L = x >> half, R = x & mask;
+      for (uint32_t r = 0; r < 4; r++) {
+        uint32_t o[4];
+        philox4x32_10(R, r, 0xFFFFFFFEu, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        uint32_t t = L ^ (o[0] & mask);
+        L = R; R = t;
+      }
+      x = (L << half) | R;
+    } while (x >= (uint32_t)U);
+    perm[a] = (int32_t)x;
   }
 }
 

@@ -59,7 +59,7 @@ def lib():
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_sample_epoch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64,
                                        C.c_uint32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_epoch_keys.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]
+        L.orc_epoch_perm.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]
         L.orc_e4m3_round_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_bf16_round.restype = C.c_float
         L.orc_bf16_round.argtypes = [C.c_float]
@@ -112,14 +112,14 @@ def sample_philox(train_lists, num_items, seed, first, B):
 
 
 def epoch_perm(seed, epoch, U):
-    keys = np.empty(U, np.int64)
-    lib().orc_epoch_keys(seed, epoch, U, _p(keys))
-    return np.argsort(keys, kind="stable").astype(np.int32)
+    """The user order of an epoch: perm[a] = the user in slot a (twin of bprx_epoch_prepare)."""
+    perm = np.empty(U, np.int32)
+    lib().orc_epoch_perm(seed, epoch, U, _p(perm))
+    return perm
 
 
 def sample_epoch(train_lists, num_items, seed, epoch, first, B):
-    """Twin of EpochWalkSampler for one epoch: the user order is the stable argsort of the Philox keys (bprx_epoch_keys), same
-    prefix sums."""
+    """Twin of EpochWalkSampler for one epoch: the user order is the keyed Feistel permutation of bprx_epoch_prepare, same prefix sums."""
     indptr, items, _ = interactions_csr(train_lists)
     U = len(train_lists)
     perm = epoch_perm(seed, epoch, U)

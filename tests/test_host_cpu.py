@@ -140,3 +140,20 @@ def test_evaluator_mirror_c1(tmp_path, golden_dir, tier):
     txt = p.read_text()
     assert hashlib.sha256(txt.encode()).hexdigest() == want["recs_sha256"]
     assert txt.splitlines()[:20] == want["recs_head"]
+
+
+def test_oracle_epoch_order_is_a_keyed_permutation():
+    """The epoch-walk samplers' user order (oracle twin of bprx_epoch_prepare): a bijection of [0, U) for every U -- powers of
+    two, their neighbours, 1 -- that changes with the epoch and with the seed and does not depend on anything else."""
+    from oracle import oracle as orc
+    for U in (1, 2, 3, 4, 5, 7, 8, 9, 255, 256, 257, 1000, 4096, 4097, 65537, 100000):
+        p = orc.epoch_perm(31, 0, U)
+        assert p.dtype == np.int32 and p.shape == (U,)
+        assert np.array_equal(np.sort(p), np.arange(U, dtype=np.int32)), U
+        assert np.array_equal(p, orc.epoch_perm(31, 0, U))
+        if U >= 255:
+            assert not np.array_equal(p, orc.epoch_perm(31, 1, U)) and not np.array_equal(p, orc.epoch_perm(32, 0, U))
+            assert not np.array_equal(p, np.arange(U))
+    # no visible structure: slot -> user correlation of a large permutation is that of a shuffle
+    p = orc.epoch_perm(5, 3, 100000).astype(np.float64)
+    assert abs(np.corrcoef(np.arange(100000), p)[0, 1]) < 0.02
