@@ -204,14 +204,21 @@ __global__ __launch_bounds__(256) void k_row_count(const int32_t *__restrict__ u
 // One group per triplet: forward scores, g = dloss/d(x+ - x-), per-occurrence gradients -> staging tables
 // (or, for rows no other triplet of the batch uses, the finished sgd update straight into the table).
 // The atomic-staging form (sparse batches, BPRMF shards, exported gradients); segment mode runs k_triplet_seg instead.
+// threads of a k_triplet_grad workgroup (its waves meet in LDS when they share a user): same-box A/B of 128 / 256 / 512 -- narrow rows
+// (G <= 32: c3shard, k = 128) want 128 (triplet kernel 57.7 -> 53.3 us, step 0.0815 -> 0.0769 ms), a triplet per wave (G = 64:
+// k = d = 256) wants 256 (c5list 192 against 200 us); 512 loses everywhere (c3shard 69 us)
+template <int G>
+struct TripletGradThreads { static constexpr int value = G == 64 ? 256 : 128; };
+
 template <int G, bool VEC>
-__global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
+__global__ __launch_bounds__(TripletGradThreads<G>::value) void k_triplet_grad(SparseArgs a, const int32_t *__restrict__ user,
                                                       const int32_t *__restrict__ pos, const int32_t *__restrict__ neg, int64_t B) {
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   // `full`: every lane group of this workgroup has a triplet (all but the last workgroup): only then may the workgroup
   // meet at barriers (user-row combination below); in a partial workgroup the surplus groups leave here
-  const bool full = ((int64_t)(blockIdx.x + 1) * 256) / G <= B;
+  constexpr int TG_T = TripletGradThreads<G>::value;
+  const bool full = ((int64_t)(blockIdx.x + 1) * TG_T) / G <= B;
   if (b >= B) return;
   // (the three index loads are issued before the first is looked at: clamp_idx's error store would otherwise order them
   //  one behind the other -- three memory round trips instead of one at the head of every wave)
@@ -317,8 +324,9 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   // order), the four wave sums meet in LDS and are added once: 256/G times fewer atomic bytes than one add per triplet
   // (at k = d = 256 a lane group IS a wave: 4x; without this the kernel is atomic-bound there).
   constexpr int WGROW = 1024;                             // floats per wave row in LDS (k + d <= WGROW)
-  __shared__ int s_u[4];
-  __shared__ __attribute__((aligned(16))) float s_du[4][WGROW];
+  constexpr int NWV = TG_T / 64;
+  __shared__ int s_u[NWV];
+  __shared__ __attribute__((aligned(16))) float s_du[NWV][WGROW];
   bool wgc = false;
   const int wv = threadIdx.x >> 6;
   if (full && k + d <= WGROW && a.wg_combine) {
@@ -326,7 +334,9 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
     const bool wave_ok = G == 64 ? !exU : comb;
     if ((threadIdx.x & 63) == 0) s_u[wv] = wave_ok ? u0 : -1 - wv;
     __syncthreads();
-    wgc = s_u[0] >= 0 && s_u[0] == s_u[1] && s_u[1] == s_u[2] && s_u[2] == s_u[3];
+    wgc = s_u[0] >= 0;
+#pragma unroll
+    for (int x = 1; x < NWV; ++x) wgc = wgc && s_u[x] == s_u[0];
   }
   // BPRMF with a workgroup-wide user (the common case in epoch order): the user-row gradient goes to LDS, so the backward
   // pass needs NO second read of the rows in the lane = element layout -- it is formed from the forward pass's registers
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
     }
   }
   if (regs_ok && __any(shI || shJ)) {             // wave-uniform entry; the LDS row belongs to this lane group alone
-    __shared__ __attribute__((aligned(16))) float s_tr[256 / G][4 * G];
+    __shared__ __attribute__((aligned(16))) float s_tr[TG_T / G][4 * G];
     float *row = s_tr[threadIdx.x / G];
     const int c4 = lane * 4;
 #pragma unroll
@@ -446,8 +456,12 @@ __global__ __launch_bounds__(256) void k_triplet_grad(SparseArgs a, const int32_
   if (wgc) {                                              // workgroup-uniform
     __syncthreads();
     const int uw = s_u[0];
-    for (int e = threadIdx.x; e < k + d; e += 256) {
-      const float sum = (s_du[0][e] + s_du[1][e]) + (s_du[2][e] + s_du[3][e]);
+    for (int e = threadIdx.x; e < k + d; e += TG_T) {
+      float sum;                                          // pairwise, in a fixed order
+      if constexpr (NWV == 2) sum = s_du[0][e] + s_du[1][e];
+      else if constexpr (NWV == 4) sum = (s_du[0][e] + s_du[1][e]) + (s_du[2][e] + s_du[3][e]);
+      else sum = ((s_du[0][e] + s_du[1][e]) + (s_du[2][e] + s_du[3][e])) + ((s_du[4 % NWV][e] + s_du[5 % NWV][e]) + (s_du[6 % NWV][e] + s_du[7 % NWV][e]));
+      static_assert(NWV == 2 || NWV == 4 || NWV == 8, "k_triplet_grad: 128, 256 or 512 threads");
       atomicAdd(e < k ? a.dGu + (size_t)uw * k + e : a.dTu + (size_t)uw * d + (e - k), sum);
     }
   }
@@ -2142,7 +2156,14 @@ int bprx_launch_triplet_grad(bprx_handle *h, const int32_t *u, const int32_t *i,
       case 32: hipLaunchKernelGGL((k_triplet_seg<32>), grid, dim3(TS_T), 0, s, a, su, u, i, j, B); break;
       default: hipLaunchKernelGGL((k_triplet_seg<64>), grid, dim3(TS_T), 0, s, a, su, u, i, j, B); break;
     }
-  } else DISPATCH_G(G, vec, k_triplet_grad, grid_for(B, G), s, a, u, i, j, B);
+  } else {
+#define TG_LAUNCH(GG, VV)                                                                                                \
+  hipLaunchKernelGGL((k_triplet_grad<GG, VV>), dim3((unsigned)((B * GG + TripletGradThreads<GG>::value - 1) / TripletGradThreads<GG>::value)), \
+                     dim3(TripletGradThreads<GG>::value), 0, s, a, u, i, j, B)
+    if (vec) { switch (G) { case 8: TG_LAUNCH(8, true); break; case 16: TG_LAUNCH(16, true); break; case 32: TG_LAUNCH(32, true); break; default: TG_LAUNCH(64, true); break; } }
+    else { switch (G) { case 8: TG_LAUNCH(8, false); break; case 16: TG_LAUNCH(16, false); break; case 32: TG_LAUNCH(32, false); break; default: TG_LAUNCH(64, false); break; } }
+#undef TG_LAUNCH
+  }
   BPRX_LAUNCH_CHECK(h, "k_triplet_grad");
   return BPRX_OK;
 }
