@@ -110,7 +110,7 @@ def lib():
         "bprx_apply_user_msgs": (C.c_int, [vp, vp, i32, i64, C.c_float, vp]),
         "bprx_sum_dense_parts": (C.c_int, [vp, vp, i32, vp]),
         "bprx_epoch_prepare": (C.c_int, [C.c_uint64, u32, i32, vp, vp, vp, vp]),
-        "bprx_epoch_slots": (C.c_int, [vp, i32, vp, vp]),
+        "bprx_epoch_slots": (C.c_int, [vp, i32, vp, i64, vp]),
         "bprx_sample_epoch": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_uint64, u32, i64, i64, vp, vp, vp, vp]),
         "bprx_index_pass_kind": (C.c_int, [vp]),
         "bprx_adam_rows": (C.c_int, [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp]),

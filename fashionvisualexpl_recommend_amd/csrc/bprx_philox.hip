@@ -148,10 +148,13 @@ __global__ __launch_bounds__(256) void k_epoch_prepare(uint32_t k0, uint32_t k1,
 }
 
 // position -> slot: positions [epoch_ptr[a], epoch_ptr[a+1]) belong to slot a (one lane group of 8 per slot)
-__global__ __launch_bounds__(256) void k_epoch_slots(const int64_t *__restrict__ epoch_ptr, int U, int32_t *__restrict__ pos_slot) {
+__global__ __launch_bounds__(256) void k_epoch_slots(const int64_t *__restrict__ epoch_ptr, int U, int32_t *__restrict__ pos_slot,
+                                                     int64_t num_pos) {
   const int a = (blockIdx.x * 256 + threadIdx.x) >> 3, lane = threadIdx.x & 7;
   if (a >= U) return;
-  const int64_t p0 = epoch_ptr[a], p1 = epoch_ptr[a + 1];
+  const int64_t p0 = epoch_ptr[a];
+  int64_t p1 = epoch_ptr[a + 1];
+  p1 = p1 < num_pos ? p1 : num_pos;                        // (never beyond the array, whatever the CSR claims)
   for (int64_t p = p0 + lane; p < p1; p += 8) pos_slot[p] = a;
 }
 
@@ -165,10 +168,10 @@ extern "C" int bprx_epoch_prepare(uint64_t seed, uint32_t epoch, int32_t num_use
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 
-extern "C" int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int32_t *pos_slot, void *stream) {
-  if (!epoch_ptr || !pos_slot || num_users <= 0) return BPRX_E_INVALID;
+extern "C" int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int32_t *pos_slot, int64_t num_pos, void *stream) {
+  if (!epoch_ptr || !pos_slot || num_users <= 0 || num_pos < 0) return BPRX_E_INVALID;
   hipLaunchKernelGGL(k_epoch_slots, dim3((unsigned)(((int64_t)num_users * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     epoch_ptr, num_users, pos_slot);
+                     epoch_ptr, num_users, pos_slot, num_pos);
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 

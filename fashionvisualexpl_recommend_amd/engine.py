@@ -406,7 +406,7 @@ class EpochWalkSampler(PhiloxSampler):
         # position -> slot of its user in the epoch order, once per epoch (4 B per interaction): saves the per-triplet
         # binary search over epoch_ptr in the kernel
         pos_slot = torch.empty(self.num_pos, dtype=torch.int32, device=self.device)
-        rc = self.lib.bprx_epoch_slots(_ptr(epoch_ptr), U, _ptr(pos_slot), _stream())
+        rc = self.lib.bprx_epoch_slots(_ptr(epoch_ptr), U, _ptr(pos_slot), self.num_pos, _stream())
         if rc < 0:
             raise _ffi.BprxError(rc, "bprx_epoch_slots failed")
         return dict(epoch=epoch, perm=perm_d, epoch_ptr=epoch_ptr, pos_slot=pos_slot)

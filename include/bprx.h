@@ -356,11 +356,11 @@ BPRX_API int bprx_sample_philox(const int64_t *indptr, const int32_t *items_sort
                          network over 2*ceil(bits(U-1)/2) bits with Philox round functions keyed by (seed, epoch), cycle-walked
                          into [0, U); CPU twin: the oracle's orc_epoch_perm), and lens[a] (int64 [num_users]) = the length of
                          that user's list; the caller's inclusive prefix sums of lens behind a leading 0 are epoch_ptr;
-     bprx_epoch_slots    pos_slot[p] = a for the positions p in [epoch_ptr[a], epoch_ptr[a+1]).
+     bprx_epoch_slots    pos_slot[p] = a for the positions p in [epoch_ptr[a], epoch_ptr[a+1]) (pos_slot: int32 [num_pos]).
    Three launches and one scan per epoch; an epoch switch never waits for the host. */
 BPRX_API int bprx_epoch_prepare(uint64_t seed, uint32_t epoch, int32_t num_users, const int64_t *indptr, int32_t *perm,
                                 int64_t *lens, void *stream);
-BPRX_API int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int32_t *pos_slot, void *stream);
+BPRX_API int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int32_t *pos_slot, int64_t num_pos, void *stream);
 BPRX_API int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
                                const int64_t *epoch_ptr, const int32_t *pos_slot, int32_t num_users, int32_t num_items, uint64_t seed,
                                uint32_t epoch, int64_t first, int64_t B, int32_t *user, int32_t *pos, int32_t *neg,
