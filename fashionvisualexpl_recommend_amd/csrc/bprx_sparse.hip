@@ -861,7 +861,7 @@ __global__ void k_clear_flags(uint32_t *f, size_t n) {
 //   * list mode: the fp32 W rows of the listed items return to zero, their multiplicities are reset when nobody else does
 //     it, and the OTHER list cursor (the one the next list-mode step appends through) is cleared.
 constexpr int DU_KB = 8;
-__global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, float *__restrict__ Bp, float *mE, float *vE,
+__global__ __launch_bounds__(1024) void k_dense_update(float *__restrict__ E, float *__restrict__ Bp, float *mE, float *vE,
                                                       float *mBp, float *vBp, const float *__restrict__ dEp,
                                                       const float *__restrict__ part, int SK, int D, int d, int PS, int adam,
                                                       float lr_t, float reg, float b1, float b2, float eps,
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     int n = *ilist_n;
     n = n < bound ? n : bound;
     const int per = PS / 4;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)n * per; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)n * per; e += (int64_t)gridDim.x * blockDim.x) {
       const int p = (int)(e / per), c4 = (int)(e % per);
       const int item = ilist[p];
       reinterpret_cast<float4 *>(W + (size_t)item * PS)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     // one thread per 4 consecutive columns: the slab reads are 16-B loads, eight slabs in flight per thread (4-B loads left
     // a block with 8 KB in flight: five round trips per tile; C2 10.7 us for 23 MB)
     const int PQ = PS >> 2;                              // PS % 16 == 0
-    for (int q = threadIdx.x; q < DU_KB * PQ; q += 256) {
+    for (int q = threadIdx.x; q < DU_KB * PQ; q += (int)blockDim.x) {
       const int kr = q / PQ, n4 = (q - kr * PQ) * 4, kk = k0 + kr;
       float nvv[4] = {0.f, 0.f, 0.f, 0.f};
       if (kk < D && n4 <= d) {
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
     }
     if (Et) {                                            // D % 128 == 0 with bf16 features: whole tiles only
       __syncthreads();
-      for (int n = threadIdx.x; n < PS; n += 256) {
+      for (int n = threadIdx.x; n < PS; n += (int)blockDim.x) {
         uint4 v;
         v.x = (uint32_t)tile[0][n] | ((uint32_t)tile[1][n] << 16);
         v.y = (uint32_t)tile[2][n] | ((uint32_t)tile[3][n] << 16);
@@ -981,23 +981,26 @@ __global__ __launch_bounds__(256) void k_dense_update(float *__restrict__ E, flo
       __syncthreads();
     }
   }
-  __shared__ double red[256];
-  red[threadIdx.x] = sq;
+  // (blockDim.x is a multiple of 64, at most 1024: a wave-level tree, then the waves' sums in a fixed order)
+  __shared__ double red[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += red[q];
+    sqpart[blockIdx.x] = t;
   }
-  if (threadIdx.x == 0) sqpart[blockIdx.x] = red[0];
   if (absmax_out) {
-    __shared__ uint32_t wm[4];
+    __shared__ uint32_t wm[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(amax, o, 64); amax = v > amax ? v : amax; }
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t b = wm[0];
-      for (int q = 1; q < 4; ++q) b = wm[q] > b ? wm[q] : b;
+      for (int q = 1; q < (int)(blockDim.x >> 6); ++q) b = wm[q] > b ? wm[q] : b;
       if (b) atomicMax(absmax_out, b);
     }
   }
@@ -2320,7 +2323,11 @@ int bprx_launch_dense_update(bprx_handle *h, float lr_t, hipStream_t s) {
   const bool images = h->cfg.feat_dtype == BPRX_F_BF16;
   const bool lm = h->list_mode != 0;
   const int64_t bound = lm ? h->list_bound : 0;
-  hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3(256), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
+  // one round per tile: a tile is DU_KB rows x PS / 4 float4 columns -- 160 threads' worth at PS = 80, 544 at PS = 272 (a 256-thread
+  // block took three dependent rounds of slab loads there: c5small 21.5 us)
+  int threads = (DU_KB * (h->PS / 4) + 63) / 64 * 64;
+  threads = threads < 256 ? 256 : (threads > 1024 ? 1024 : threads);
+  hipLaunchKernelGGL(k_dense_update, dim3(blocks), dim3((unsigned)threads), 0, s, h->t.E, h->t.Bp, h->t.m_E, h->t.v_E, h->t.m_Bp,
                      h->t.v_Bp, h->dEp, part, h->SK_step, D, h->cfg.embed_d, h->PS,
                      h->cfg.optimizer == BPRX_OPT_ADAM_TF23 ? 1 : 0, lr_t, h->cfg.reg, h->cfg.beta1, h->cfg.beta2,
                      h->cfg.epsilon, h->loss_acc, gscale, images ? (uint16_t *)h->Et : (uint16_t *)nullptr, (uint16_t *)h->EtF,
