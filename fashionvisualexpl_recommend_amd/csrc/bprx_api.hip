@@ -167,14 +167,19 @@ extern "C" int bprx_create(const bprx_config *cfg, bprx_handle **out) {
       // chunk list: the owners' regions (one slot per item + 4 per owner, <= 1024 owners; a last partial range) + the overflow list
       h->seg_lead_cap = (int64_t)(I + 8192 + 4 * 1024 + 2 * MB / 64 + 64 + 64);
       h->seg_ent_cap = (int64_t)(6 * MB + 64 * 1024 + 2048);
+    // byte planes for the index pass (bprx_sample_*_h): at most 256 owners of 2^shift items; BPRX_IDX8=0: none (A/B)
+    h->idx8_shift = 0;
+    if (!(getenv("BPRX_IDX8") && atoi(getenv("BPRX_IDX8")) == 0))
+      for (int sh = 8; sh <= 13 && !h->idx8_shift; ++sh)
+        if ((((int64_t)I - 1) >> sh) <= 255) h->idx8_shift = sh;
       bool ok2 = dalloc_zero(&h->seg_rank, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->seg_cnt, I) == hipSuccess &&
                  dalloc_zero(&h->seg_ptr, I) == hipSuccess && dalloc_zero(&h->seg_cursor, (size_t)6) == hipSuccess &&
                  dalloc_zero((int4 **)&h->seg_lead, (size_t)h->seg_lead_cap) == hipSuccess &&
                  dalloc_zero(&h->hot_done, I) == hipSuccess && dalloc_zero((int2 **)&h->seg_ent, (size_t)h->seg_ent_cap) == hipSuccess &&
                  dalloc_zero(&h->uslot_of, U) == hipSuccess && dalloc_zero(&h->ulist, MB) == hipSuccess &&
                  dalloc_zero(&h->uold, MB * (k + d)) == hipSuccess &&
-                 (I > 65536 || (getenv("BPRX_IDX8") && atoi(getenv("BPRX_IDX8")) == 0) ||     // BPRX_IDX8=0: no byte planes (A/B)
-                  (dalloc_zero(&h->own8, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->loc8, (size_t)2 * MB) == hipSuccess));
+                 (!h->idx8_shift ||
+                  (dalloc_zero(&h->own8, (size_t)2 * MB) == hipSuccess && dalloc_zero(&h->loc8, (size_t)2 * MB * (h->idx8_shift > 8 ? 2 : 1)) == hipSuccess));
       if (!ok2) {
         snprintf(g_create_err, sizeof(g_create_err), "segment scratch allocation failed");
         free_scratch(h);

@@ -77,10 +77,11 @@ struct bprx_handle {
   int32_t *ulist;                 // [max_batch] the batch's users (first-run order): walked by k_item_seg's finishing groups
   float *uold;                    // [max_batch][k + d] pre-update [gamma_u | theta_u] of the slot's user
   // byte planes of the item ids of the NEXT step's batch, written by the library's own device samplers (bprx_sample_*_h) when
-  // num_items <= 65 536: own8 = id >> 8 (the owner workgroup of k_index_seg, 256 items each), loc8 = id & 255; [2 * max_batch]
+  // own8 = id >> idx8_shift (the owner workgroup of k_index_seg, 2^shift items each: at most 256 owners), loc8 = the rest; [2 * max_batch]
   // each (positives, then negatives).  idx8_pos / idx8_neg / idx8_B: the buffers and batch size they belong to; idx8_n: triplets
   // filled so far (-1: invalid); consumed (idx8_n = 0) by the step that uses them.
   uint8_t *own8, *loc8;
+  int idx8_shift;                 // own8 = id >> idx8_shift (8: loc8 holds bytes; 9..13, num_items up to 2 M: loc8 holds uint16 id & (2^shift - 1))
   const int32_t *idx8_pos, *idx8_neg;
   int64_t idx8_B, idx8_n;
   bool idx8_use;                  // this step's index pass scans the byte planes

@@ -26,12 +26,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// the owner plane (id >> sh: one byte) and the local plane (id & (2^sh - 1): a byte at sh == 8, else 16 bits) of a triplet's items
+__device__ __forceinline__ void put_planes(uint8_t *__restrict__ own8, uint8_t *__restrict__ loc8, long long pi, long long pj,
+                                           int32_t ii, int32_t jj, int sh) {
+  own8[pi] = (uint8_t)(ii >> sh); own8[pj] = (uint8_t)(jj >> sh);
+  if (sh == 8) { loc8[pi] = (uint8_t)ii; loc8[pj] = (uint8_t)jj; }
+  else {
+    uint16_t *l16 = reinterpret_cast<uint16_t *>(loc8);
+    const int m = (1 << sh) - 1;
+    l16[pi] = (uint16_t)(ii & m); l16[pj] = (uint16_t)(jj & m);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict__ indptr, const int32_t *__restrict__ items,
                                                        const int32_t *__restrict__ pos_user, unsigned long long N, uint32_t I,
                                                        uint32_t k0, uint32_t k1, unsigned long long first, long long B,
                                                        int32_t *__restrict__ u, int32_t *__restrict__ i, int32_t *__restrict__ j,
                                                        uint8_t *__restrict__ own8, uint8_t *__restrict__ loc8, long long pl_i,
-                                                       long long pl_j) {
+                                                       long long pl_j, int sh) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const unsigned long long n = first + (unsigned long long)b;
@@ -55,10 +67,7 @@ __global__ __launch_bounds__(256) void k_sample_philox(const int64_t *__restrict
   }
   const int32_t ii = items[p];
   u[b] = uu; i[b] = ii; j[b] = jj;
-  if (own8) {                                           // byte planes of the item ids for the handle's index pass (k_index_seg)
-    own8[pl_i + b] = (uint8_t)(ii >> 8); loc8[pl_i + b] = (uint8_t)ii;
-    own8[pl_j + b] = (uint8_t)(jj >> 8); loc8[pl_j + b] = (uint8_t)jj;
-  }
+  if (own8) put_planes(own8, loc8, pl_i + b, pl_j + b, ii, jj, sh);   // byte planes of the item ids for the handle's index pass
 }
 
 // Epoch-walk mode (the reference's order, dataset.py:93-107, as a stateless stream): within epoch e the users come in the
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
                                                       long long first, long long B, int32_t *__restrict__ u,
                                                       int32_t *__restrict__ i, int32_t *__restrict__ j,
                                                       uint8_t *__restrict__ own8, uint8_t *__restrict__ loc8, long long pl_i,
-                                                      long long pl_j) {
+                                                      long long pl_j, int sh) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const long long n = first + b;
@@ -100,10 +109,7 @@ __global__ __launch_bounds__(256) void k_sample_epoch(const int64_t *__restrict_
   }
   const int32_t ii = lst[n - epoch_ptr[lo]];
   u[b] = uu; i[b] = ii; j[b] = jj;
-  if (own8) {
-    own8[pl_i + b] = (uint8_t)(ii >> 8); loc8[pl_i + b] = (uint8_t)ii;
-    own8[pl_j + b] = (uint8_t)(jj >> 8); loc8[pl_j + b] = (uint8_t)jj;
-  }
+  if (own8) put_planes(own8, loc8, pl_i + b, pl_j + b, ii, jj, sh);
 }
 
 // The user order of an epoch: a keyed permutation of [0, U) evaluated POINTWISE -- slot a of epoch `epoch` holds user
@@ -182,8 +188,8 @@ extern "C" int bprx_epoch_slots(const int64_t *epoch_ptr, int32_t num_users, int
 // triplets [batch_offset, batch_offset + B) of a batch of batch_size (an epoch crossing fills a batch in two calls); the planes
 // are valid for the step that is called with exactly these buffers and B = batch_size, and are consumed by it.
 static void plane_args(bprx_handle *h, const int32_t *pos, const int32_t *neg, int64_t B, int64_t batch_offset, int64_t batch_size,
-                       uint8_t **own8, uint8_t **loc8, long long *pl_i, long long *pl_j) {
-  *own8 = nullptr; *loc8 = nullptr; *pl_i = 0; *pl_j = 0;
+                       uint8_t **own8, uint8_t **loc8, long long *pl_i, long long *pl_j, int *sh) {
+  *own8 = nullptr; *loc8 = nullptr; *pl_i = 0; *pl_j = 0; *sh = 8;
   if (!h || !h->own8 || batch_size <= 0 || batch_size > h->cfg.max_batch || batch_offset < 0 || batch_offset + B > batch_size) return;
   if (batch_offset == 0) { h->idx8_pos = pos; h->idx8_neg = neg; h->idx8_B = batch_size; h->idx8_n = 0; }
   else if (h->idx8_n < 0 || h->idx8_B != batch_size || pos != h->idx8_pos + batch_offset || neg != h->idx8_neg + batch_offset) {
@@ -191,7 +197,7 @@ static void plane_args(bprx_handle *h, const int32_t *pos, const int32_t *neg, i
     return;
   }
   h->idx8_n += B;
-  *own8 = h->own8; *loc8 = h->loc8; *pl_i = batch_offset; *pl_j = batch_size + batch_offset;
+  *own8 = h->own8; *loc8 = h->loc8; *pl_i = batch_offset; *pl_j = batch_size + batch_offset; *sh = h->idx8_shift;
 }
 
 extern "C" int bprx_sample_epoch_h(bprx_handle *h, const int64_t *indptr, const int32_t *items_sorted, const int32_t *perm,
@@ -204,10 +210,11 @@ extern "C" int bprx_sample_epoch_h(bprx_handle *h, const int64_t *indptr, const 
   if (B == 0) return BPRX_OK;
   uint8_t *own8, *loc8;
   long long pl_i, pl_j;
-  plane_args(h, pos, neg, B, batch_offset, batch_size, &own8, &loc8, &pl_i, &pl_j);
+  int sh;
+  plane_args(h, pos, neg, B, batch_offset, batch_size, &own8, &loc8, &pl_i, &pl_j, &sh);
   hipLaunchKernelGGL(k_sample_epoch, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
                      items_sorted, perm, epoch_ptr, pos_slot, num_users, (uint32_t)num_items, (uint32_t)seed, (uint32_t)(seed >> 32),
-                     epoch, (long long)first, (long long)B, user, pos, neg, own8, loc8, pl_i, pl_j);
+                     epoch, (long long)first, (long long)B, user, pos, neg, own8, loc8, pl_i, pl_j, sh);
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 
@@ -227,10 +234,11 @@ extern "C" int bprx_sample_philox_h(bprx_handle *h, const int64_t *indptr, const
   if (B == 0) return BPRX_OK;
   uint8_t *own8, *loc8;
   long long pl_i, pl_j;
-  plane_args(h, pos, neg, B, batch_offset, batch_size, &own8, &loc8, &pl_i, &pl_j);
+  int sh;
+  plane_args(h, pos, neg, B, batch_offset, batch_size, &own8, &loc8, &pl_i, &pl_j, &sh);
   hipLaunchKernelGGL(k_sample_philox, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, indptr,
                      items_sorted, pos_user, (unsigned long long)num_pos, (uint32_t)num_items, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), (unsigned long long)first, (long long)B, user, pos, neg, own8, loc8, pl_i, pl_j);
+                     (uint32_t)(seed >> 32), (unsigned long long)first, (long long)B, user, pos, neg, own8, loc8, pl_i, pl_j, sh);
   return hipGetLastError() == hipSuccess ? BPRX_OK : BPRX_E_HIP;
 }
 

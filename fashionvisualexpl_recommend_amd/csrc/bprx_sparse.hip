@@ -1081,6 +1081,7 @@ struct IndexSegArgs {
   // byte planes of the batch's item ids (positives, then negatives; written by bprx_sample_*_h) or nullptr.  With them
   // R == 256 and B % 16 == 0: owner w scans own8 for bytes equal to w, sixteen values per 16-byte load.
   const uint8_t *own8, *loc8;
+  int wide;                       // loc8 holds 16-bit locals (R = 2^shift > 256 items per owner: num_items > 65 536)
 };
 
 __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
@@ -1145,7 +1146,48 @@ __global__ __launch_bounds__(IX_T) void k_index_seg(IndexSegArgs a) {
     const unsigned mn = min(min(x0, x1), min(x2, x3));
     if (in && mn <= Wm) { one(v.x, occ); one(v.y, occ + 1); one(v.z, occ + 2); one(v.w, occ + 3); }
   };
-  if (a.own8) {
+  if (a.own8 && a.wide) {
+    // as below with 16-bit locals (two 16-byte loads of the local plane per load of the owner plane; four loads in flight)
+    const uint4 *o4 = reinterpret_cast<const uint4 *>(a.own8), *l4 = reinterpret_cast<const uint4 *>(a.loc8);
+    const int n16 = (int)((2 * a.B) >> 4);
+    const int nblk = (n16 + IX_T - 1) / IX_T;
+    const int rot = nblk ? (int)((((unsigned)w * 2654435761u) >> 8) % (unsigned)nblk) : 0;
+    const unsigned wp = (unsigned)w * 0x01010101u;
+    auto dword16 = [&](unsigned o, unsigned la, unsigned lb, int occ) {       // la: locals of bytes 0, 1; lb: of bytes 2, 3
+      const unsigned y = o ^ wp;
+      unsigned m = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+      while (m) {
+        const int by = (__ffs((int)m) - 1) >> 3;
+        const unsigned l = ((by < 2 ? la : lb) >> (16 * (by & 1))) & 0xffffu;
+        a.seg_rank[occ + by] = atomicAdd(&cnt[l < (unsigned)Rw ? l : (unsigned)Rw - 1u], 1);
+        m &= m - 1;
+      }
+    };
+    for (int blk = 0; blk < nblk; blk += 4) {
+      uint4 vo[4], va[4], vb[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        int bb = blk + x + rot;
+        bb = bb >= nblk ? bb - nblk : bb;
+        const int e = bb * IX_T + tid;
+        const int ec = e < n16 ? e : n16 - 1;
+        vo[x] = o4[ec]; va[x] = l4[2 * ec]; vb[x] = l4[2 * ec + 1];
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        int bb = blk + x + rot;
+        bb = bb >= nblk ? bb - nblk : bb;
+        const int e = bb * IX_T + tid;
+        const unsigned y0 = vo[x].x ^ wp, y1 = vo[x].y ^ wp, y2 = vo[x].z ^ wp, y3 = vo[x].w ^ wp;
+        const unsigned any = (((y0 - 0x01010101u) & ~y0) | ((y1 - 0x01010101u) & ~y1) | ((y2 - 0x01010101u) & ~y2) |
+                              ((y3 - 0x01010101u) & ~y3)) & 0x80808080u;
+        if (blk + x < nblk && e < n16 && any) {
+          dword16(vo[x].x, va[x].x, va[x].y, 16 * e); dword16(vo[x].y, va[x].z, va[x].w, 16 * e + 4);
+          dword16(vo[x].z, vb[x].x, vb[x].y, 16 * e + 8); dword16(vo[x].w, vb[x].z, vb[x].w, 16 * e + 12);
+        }
+      }
+    }
+  } else if (a.own8) {
     // one byte per occurrence: y = plane ^ (w in every byte) has a zero byte where the occurrence is mine; the classic
     // (y - 0x01..) & ~y & 0x80.. test is exact for "any zero byte in the dword", and the four dwords of a load are OR-ed before
     // the one compare.  A lane with a match (16 values in `nown`) finds the bytes with the exact per-byte mask and ranks them;
@@ -2098,9 +2140,11 @@ int bprx_launch_index_pass(bprx_handle *h, const int32_t *u, const int32_t *i, c
     if ((a.I + nown - 1) / nown > IX_RMAX) nown = (a.I + IX_RMAX - 1) / IX_RMAX;   // ... more when a range would not fit LDS
     if (nown > a.I) nown = a.I;
     x.R = (a.I + nown - 1) / nown;
-    x.own8 = x.loc8 = nullptr;
+    x.own8 = x.loc8 = nullptr; x.wide = 0;
     h->idx_kind = 1;
-    if (h->idx8_use && a.I <= 65536) { x.R = 256; x.own8 = h->own8; x.loc8 = h->loc8; h->idx_kind = 2; }    // the sampler left byte planes of this batch
+    if (h->idx8_use && h->idx8_shift) {                                          // the sampler left byte planes of this batch
+      x.R = 1 << h->idx8_shift; x.own8 = h->own8; x.loc8 = h->loc8; x.wide = h->idx8_shift > 8; h->idx_kind = 2;
+    }    // the sampler left byte planes of this batch
     x.nown = (a.I + x.R - 1) / x.R;
     x.seg_rank = h->seg_rank; x.seg_cnt = h->seg_cnt; x.seg_ptr = h->seg_ptr;
     x.Ce = (int)(2 * ((2 * B + x.nown - 1) / x.nown) + 64);

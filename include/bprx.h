@@ -367,8 +367,8 @@ BPRX_API int bprx_sample_epoch(const int64_t *indptr, const int32_t *items_sorte
                                void *stream);
 
 /* The same two samplers, told which handle's NEXT step will consume the batch (h may be NULL: exactly the calls above).
-   When that handle steps in segment mode with num_items <= 65 536, the sampler also writes the high and the low byte of every
-   sampled item id into byte planes the handle owns (2 B per occurrence); the index pass of the step called with exactly these
+   When that handle steps in segment mode (num_items up to 2 M), the sampler also writes the owner byte (id >> shift, shift = 8 up to
+   65 536 items) and the local part (a byte, or 16 bits) of every sampled item id into planes the handle owns (2-3 B per occurrence); the index pass of the step called with exactly these
    pos / neg pointers and B == batch_size (a multiple of 16) then scans one byte per occurrence instead of four (its owner
    workgroups each read the whole batch).  batch_offset / batch_size: this call fills triplets [batch_offset, batch_offset + B)
    of a batch of batch_size, whose arrays start at user - batch_offset, pos - batch_offset, neg - batch_offset (an epoch

@@ -90,6 +90,35 @@ def test_segment_step_reports_out_of_range_indices_without_faulting(monkeypatch)
     assert all(np.isfinite(e.t[n].cpu().numpy()).all() for n in ("Gu", "Gi", "Bi"))
 
 
+def test_index_pass_on_wide_byte_planes(monkeypatch):
+    """More than 65 536 items: the owner plane is id >> shift (at most 256 owners of 2^shift items), the local plane 16 bits.
+    70 000 items -> shift 9 (137 owners of 512, the last one partial); ids at both ends and a hot item included."""
+    monkeypatch.setenv("BPRX_ITEM_MODE", "2")
+    from fashionvisualexpl_recommend_amd.engine import Engine, EpochWalkSampler
+    U, I, k, B = 400, 70000, 32, 1024
+    t = _tables(U, I, k, 0, 0, seed=11)
+    lr, reg = 0.05, 1e-3
+    e = Engine(model="bprmf", num_users=U, num_items=I, embed_k=k, optimizer="sgd", lr=lr, reg=reg, max_batch=B).bind(**t)
+    o = orc.OracleModel(**t, quant=0)
+    rs = np.random.RandomState(4)
+    lists = []
+    for u in range(U):
+        l = set(rs.choice(I, size=9, replace=False).tolist())
+        l.add(0 if u % 3 == 0 else I - 1)                     # both ends of the id range; item 0 / I-1 are hot
+        l.add(65536 + (u % 5))                                # ids just above the 16-bit boundary
+        lists.append(sorted(l))
+    smp = EpochWalkSampler(lists, I, seed=8).feeds(e)
+    for step in range(5):                                   # 4 400 positives: a step crosses the epoch boundary
+        u, i, j = smp.sample(B)
+        loss = e.step(u, i, j).item()
+        assert e.lib.bprx_index_pass_kind(e.h) == 2, step
+        want = o.step(u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy(), "sgd", lr, reg)
+        assert loss == pytest.approx(want, rel=2e-5), step
+        for n in ("Gu", "Gi", "Bi"):
+            np.testing.assert_allclose(e.t[n].cpu().numpy().reshape(-1), getattr(o, n).reshape(-1), rtol=2e-5, atol=2e-6, err_msg="%s %d" % (n, step))
+    e.sync_check()
+
+
 @pytest.mark.parametrize("kind", ["epoch", "philox"])
 def test_index_pass_on_the_samplers_byte_planes(kind, monkeypatch):
     """bprx_sample_*_h leave the byte planes of the item ids; the step on exactly that batch scans them (kind 2) and must give
